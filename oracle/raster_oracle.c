@@ -1,0 +1,320 @@
+/* ORACLE (test infrastructure only) -- scalar CPU restatement of the reference's per-frame draw.
+ *
+ * What is restated (reference has no CPU rasteriser; glium/OpenGL does this work):
+ *   - vertex stage      assets/shaders/static.vert:25-45
+ *   - fixed function    engine/src/renderer.rs:49-57 (depth LESS + write, cull clockwise),
+ *                       engine/src/window.rs:12,40-44 (24-bit depth, clear depth 1.0),
+ *                       engine/src/meshes.rs:97-106 (TrianglesList, u32 indices),
+ *                       draw order game/src/level.rs:443-496 (earlier primitive wins depth ties)
+ *   - fragment stage    assets/shaders/static.frag:18-28 with samplers game_shaders.rs:133-142
+ *                       (palette CLAMP/NEAREST) and :395-404 (atlas REPEAT/NEAREST)
+ *   - sky               assets/shaders/sky.vert:9-16, sky.frag:12-26 (KIND_SKY)
+ *
+ * OpenGL leaves sub-ulp behaviour to the driver, so "the arithmetic" is pinned HERE and in
+ * DESIGN.md section "Raster arithmetic" -- binary32, explicit operation order, fmaf only where
+ * written, no contraction (build with -ffp-contract=off).  The HIP kernels are written
+ * independently against that text; this file is the checker.  It is never linked into the product.
+ *
+ * PARITY PIN STATUS: parity unpinned against a GL readback (no GL/Rust here); pinned by analytic
+ * KATs (tests/test_kat_analytic.py) and golden digests (tests/golden/).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KIND_FLAT 0u
+#define KIND_WALL 1u
+#define KIND_DECOR 2u
+#define KIND_SKY 3u
+
+typedef struct {
+  float a_pos[3];
+  float a_atlas_uv[2];
+  float a_tile_uv[2];
+  float a_tile_size[2];
+  float a_scroll_rate;
+  float a_row_height;
+  uint8_t a_num_frames;
+  uint8_t a_light;
+  uint8_t pad[2];
+} StaticVertex; /* game/src/vertex.rs:5-16, 48 bytes */
+
+typedef struct {
+  uint32_t kind, object_id, first_index, index_count;
+} Draw;
+
+typedef struct {
+  const StaticVertex *static_verts;
+  const uint32_t *static_indices;
+  const float *sky_verts; /* xyz triples */
+  const uint32_t *sky_indices;
+  const Draw *draws;
+  uint32_t n_draws;
+  const uint8_t *flat_atlas;
+  uint32_t flat_w, flat_h;
+  const uint16_t *wall_atlas;
+  uint32_t wall_w, wall_h;
+  const uint16_t *sky_tex;
+  uint32_t sky_w, sky_h;
+  float sky_band;
+  const uint8_t *colormap; /* 32*256 */
+} OracleLevel;
+
+typedef struct {
+  float e[3][3];  /* edge functions  e_i = fma(A,px,fma(B,py,C)) */
+  float zp[3];    /* window depth plane */
+  float wp[3];    /* 1/w plane */
+  float up[3], vp[3]; /* u/w, v/w planes */
+  int tl[3];
+  int x0, y0, x1, y1; /* inclusive pixel bbox */
+  uint32_t kind;
+  float atlas_u, atlas_v, size_x, size_y, light;
+} Setup;
+
+static float glsl_mod(float x, float y) { return x - y * floorf(x / y); }
+
+/* static.vert:27-39 : animation-frame atlas offset (flat varying) */
+static void atlas_uv_at(const StaticVertex *v, float time, float atlas_w, float *au, float *av) {
+  if (v->a_num_frames == 1) {
+    *au = v->a_atlas_uv[0];
+    *av = v->a_atlas_uv[1];
+    return;
+  }
+  const float anim_fps = 8.0f / 35.0f;
+  float frame_index = time / anim_fps;
+  frame_index = floorf(glsl_mod(frame_index, (float)v->a_num_frames));
+  float atlas_u = v->a_atlas_uv[0] + frame_index * v->a_tile_size[0];
+  float n_rows_down = ceilf((atlas_u + v->a_tile_size[0]) / atlas_w) - 1.0f;
+  atlas_u = atlas_u + glsl_mod(atlas_w - v->a_atlas_uv[0], v->a_tile_size[0]) * n_rows_down;
+  *au = atlas_u;
+  *av = v->a_atlas_uv[1] + n_rows_down * v->a_row_height;
+}
+
+static void mat_mul(const float *p, const float *m, float *pm) { /* column-major, (P*M)[c][r] */
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++)
+      pm[c * 4 + r] = ((p[0 * 4 + r] * m[c * 4 + 0] + p[1 * 4 + r] * m[c * 4 + 1]) + p[2 * 4 + r] * m[c * 4 + 2]) +
+                      p[3 * 4 + r] * m[c * 4 + 3];
+}
+
+static void xform(const float *pm, const float *pos, float *clip) {
+  for (int r = 0; r < 4; r++)
+    clip[r] = fmaf(pm[8 + r], pos[2], fmaf(pm[4 + r], pos[1], fmaf(pm[0 + r], pos[0], pm[12 + r])));
+}
+
+static float dop(float a, float b, float c, float d) { /* a*b - c*d, each product rounded (symmetric) */
+  float p = a * b, q = c * d;
+  return p - q;
+}
+
+/* Triangle setup: DESIGN.md "Raster arithmetic" steps S1..S6.  Returns 0 if culled. */
+static int setup_tri(const float clip[3][4], const float u[3], const float v[3], int width, int height, Setup *s) {
+  if (clip[0][3] <= 0.0f && clip[1][3] <= 0.0f && clip[2][3] <= 0.0f) return 0;
+  const float hw = 0.5f * (float)width, hh = 0.5f * (float)height;
+  float xw[3], yw[3], w[3];
+  for (int i = 0; i < 3; i++) {
+    xw[i] = (clip[i][0] + clip[i][3]) * hw;
+    yw[i] = (clip[i][1] + clip[i][3]) * hh;
+    w[i] = clip[i][3];
+  }
+  for (int i = 0; i < 3; i++) {
+    int j = (i + 1) % 3, k = (i + 2) % 3;
+    s->e[i][0] = dop(yw[j], w[k], yw[k], w[j]);
+    s->e[i][1] = dop(xw[k], w[j], xw[j], w[k]);
+    s->e[i][2] = dop(xw[j], yw[k], xw[k], yw[j]);
+    s->tl[i] = (s->e[i][0] > 0.0f) || (s->e[i][0] == 0.0f && s->e[i][1] > 0.0f);
+  }
+  float det = fmaf(w[0], s->e[0][2], fmaf(yw[0], s->e[0][1], xw[0] * s->e[0][0]));
+  if (!(det > 0.0f)) return 0; /* cull clockwise + degenerate (renderer.rs:55) */
+  for (int c = 0; c < 3; c++) {
+    float nz = fmaf(clip[2][2], s->e[2][c], fmaf(clip[1][2], s->e[1][c], clip[0][2] * s->e[0][c]));
+    float n1 = (s->e[0][c] + s->e[1][c]) + s->e[2][c];
+    float nu = fmaf(u[2], s->e[2][c], fmaf(u[1], s->e[1][c], u[0] * s->e[0][c]));
+    float nv = fmaf(v[2], s->e[2][c], fmaf(v[1], s->e[1][c], v[0] * s->e[0][c]));
+    s->zp[c] = 0.5f * (nz / det);
+    s->wp[c] = n1 / det;
+    s->up[c] = nu / det;
+    s->vp[c] = nv / det;
+  }
+  s->zp[2] = s->zp[2] + 0.5f;
+  /* bbox: part of the coverage definition */
+  float wmin = fminf(w[0], fminf(w[1], w[2]));
+  s->x0 = 0;
+  s->y0 = 0;
+  s->x1 = width - 1;
+  s->y1 = height - 1;
+  if (wmin >= 1e-5f) {
+    float sx[3], sy[3];
+    for (int i = 0; i < 3; i++) {
+      sx[i] = xw[i] / w[i];
+      sy[i] = yw[i] / w[i];
+    }
+    float fx0 = floorf(fminf(sx[0], fminf(sx[1], sx[2]))) - 1.0f;
+    float fx1 = ceilf(fmaxf(sx[0], fmaxf(sx[1], sx[2]))) + 1.0f;
+    float fy0 = floorf(fminf(sy[0], fminf(sy[1], sy[2]))) - 1.0f;
+    float fy1 = ceilf(fmaxf(sy[0], fmaxf(sy[1], sy[2]))) + 1.0f;
+    if (!(fx0 <= (float)(width - 1) && fx1 >= 0.0f && fy0 <= (float)(height - 1) && fy1 >= 0.0f)) return 0;
+    s->x0 = (int)fmaxf(fx0, 0.0f);
+    s->y0 = (int)fmaxf(fy0, 0.0f);
+    s->x1 = (int)fminf(fx1, (float)(width - 1));
+    s->y1 = (int)fminf(fy1, (float)(height - 1));
+  }
+  return 1;
+}
+
+static float plane(const float *p, float px, float py) { return fmaf(p[0], px, fmaf(p[1], py, p[2])); }
+
+/* static.frag:19-20 texel fetch.  Returns the raw texel (u16; flats are promoted, never transparent). */
+static uint32_t fetch_texel(const OracleLevel *L, const Setup *s, float px, float py, float *dist) {
+  float rw = plane(s->wp, px, py);
+  float w = 1.0f / rw;
+  float tu = plane(s->up, px, py) * w;
+  float tv = plane(s->vp, px, py) * w;
+  *dist = w;
+  float uvx = glsl_mod(tu, s->size_x) + s->atlas_u;
+  float uvy = glsl_mod(tv, s->size_y) + s->atlas_v;
+  int ix = (int)floorf(uvx), iy = (int)floorf(uvy);
+  if (s->kind == KIND_FLAT) {
+    return L->flat_atlas[(size_t)(iy & (int)(L->flat_h - 1)) * L->flat_w + (size_t)(ix & (int)(L->flat_w - 1))];
+  }
+  return L->wall_atlas[(size_t)(iy & (int)(L->wall_h - 1)) * L->wall_w + (size_t)(ix & (int)(L->wall_w - 1))];
+}
+
+/* static.frag:24-26 */
+static uint8_t shade(const OracleLevel *L, uint32_t idx, float v_light, float dist) {
+  float dist_term = fminf(1.0f, 1.0f - 0.9f / (dist + 0.9f));
+  float light = v_light * 2.0f - dist_term;
+  float t = (1.0f - light) * 32.0f;
+  int row = t < 0.0f ? 0 : (t >= 32.0f ? 31 : (int)floorf(t));
+  return L->colormap[row * 256 + (int)idx];
+}
+
+/* sky.frag:12-26.  v_p = clip position interpolated (x/w, y/w are NDC), v_r flat per pose. */
+static uint8_t shade_sky(const OracleLevel *L, float px, float py, int width, int height, const float *vr) {
+  float ndc_x = px / (0.5f * (float)width) - 1.0f;
+  float ndc_y = py / (0.5f * (float)height) - 1.0f;
+  float uvx = ndc_x;
+  float uvy = -ndc_y;
+  uvx = uvx - 4.0f * vr[0] / 3.14159265358f;
+  uvy = (uvy + 1.0f) + vr[1];
+  float band = L->sky_band;
+  if (uvy < 0.0f) {
+    uvy = fabsf(glsl_mod(-uvy + band, band * 2.0f) - band);
+  } else if (uvy >= 2.0f) {
+    uvy = fabsf(glsl_mod((uvy - 2.0f) + band, band * 2.0f) - band);
+  } else if (uvy >= 1.0f) {
+    uvy = 1.0f - uvy;
+  }
+  /* REPEAT + NEAREST on normalised coordinates */
+  float fx = uvx - floorf(uvx), fy = uvy - floorf(uvy);
+  int ix = (int)floorf(fx * (float)L->sky_w), iy = (int)floorf(fy * (float)L->sky_h);
+  if (ix >= (int)L->sky_w) ix = (int)L->sky_w - 1;
+  if (iy >= (int)L->sky_h) iy = (int)L->sky_h - 1;
+  uint32_t texel = L->sky_tex[(size_t)iy * L->sky_w + (size_t)ix];
+  return L->colormap[texel & 0xFF]; /* palette row v = 0 -> colormap 0 */
+}
+
+#define NO_PRIM 0xFFFFFFFFu
+
+/* Renders one pose.  out_fb: height*width bytes, row 0 = bottom (glReadPixels order).
+ * out_prim (optional): winning primitive id per pixel or NO_PRIM.  kinds_mask: bit k enables KIND k. */
+int oracle_render(const OracleLevel *L, const float *modelview, const float *projection, float time,
+                  const uint8_t *lights, int width, int height, uint32_t kinds_mask, uint8_t *out_fb,
+                  uint32_t *out_prim) {
+  size_t npx = (size_t)width * (size_t)height;
+  uint32_t *depth = (uint32_t *)malloc(npx * sizeof(uint32_t));
+  uint32_t *prim = (uint32_t *)malloc(npx * sizeof(uint32_t));
+  if (!depth || !prim) return -1;
+  for (size_t i = 0; i < npx; i++) {
+    depth[i] = 0xFFFFFFFFu;
+    prim[i] = NO_PRIM;
+  }
+  memset(out_fb, 0, npx);
+  float pm[16];
+  mat_mul(projection, modelview, pm);
+  /* sky.vert:10-12 */
+  float vr[2];
+  vr[0] = atan2f(pm[8], pm[10]);
+  vr[1] = pm[9] / pm[11];
+  uint32_t prim_id = 0;
+  for (uint32_t d = 0; d < L->n_draws; d++) {
+    const Draw *dr = &L->draws[d];
+    uint32_t ntri = dr->index_count / 3;
+    if (!((kinds_mask >> dr->kind) & 1u) || dr->kind == KIND_DECOR) {
+      prim_id += ntri;
+      continue;
+    }
+    for (uint32_t t = 0; t < ntri; t++, prim_id++) {
+      float clip[3][4], u[3] = {0, 0, 0}, v[3] = {0, 0, 0};
+      Setup s;
+      s.kind = dr->kind;
+      if (dr->kind == KIND_SKY) {
+        for (int i = 0; i < 3; i++) xform(pm, &L->sky_verts[3 * L->sky_indices[dr->first_index + 3 * t + i]], clip[i]);
+      } else {
+        const StaticVertex *vv[3];
+        for (int i = 0; i < 3; i++) {
+          vv[i] = &L->static_verts[L->static_indices[dr->first_index + 3 * t + i]];
+          xform(pm, vv[i]->a_pos, clip[i]);
+          u[i] = vv[i]->a_tile_uv[0] + time * vv[i]->a_scroll_rate; /* static.vert:26 */
+          v[i] = vv[i]->a_tile_uv[1];
+        }
+        const StaticVertex *pv = vv[2]; /* flat varyings: provoking (last) vertex */
+        float aw = dr->kind == KIND_FLAT ? (float)L->flat_w : (float)L->wall_w;
+        atlas_uv_at(pv, time, aw, &s.atlas_u, &s.atlas_v);
+        s.size_x = pv->a_tile_size[0];
+        s.size_y = pv->a_tile_size[1];
+        s.light = (float)lights[pv->a_light] / 255.0f; /* static.vert:43 texelFetch of R8 unorm */
+      }
+      if (!setup_tri(clip, u, v, width, height, &s)) continue;
+      for (int iy = s.y0; iy <= s.y1; iy++) {
+        float py = (float)iy + 0.5f;
+        for (int ix = s.x0; ix <= s.x1; ix++) {
+          float px = (float)ix + 0.5f;
+          int inside = 1;
+          for (int i = 0; i < 3 && inside; i++) {
+            float e = plane(s.e[i], px, py);
+            inside = (e > 0.0f) || (e == 0.0f && s.tl[i]);
+          }
+          if (!inside) continue;
+          float zw = plane(s.zp, px, py);
+          if (!(zw >= 0.0f && zw <= 1.0f)) continue;
+          float rw = plane(s.wp, px, py);
+          if (!(rw > 0.0f)) continue;
+          uint32_t d24 = (uint32_t)fmaf(zw, 16777215.0f, 0.5f);
+          size_t o = (size_t)iy * (size_t)width + (size_t)ix;
+          if (!(d24 < depth[o])) continue; /* LESS: the earlier primitive keeps ties */
+          uint8_t colour;
+          if (dr->kind == KIND_SKY) {
+            colour = shade_sky(L, px, py, width, height, vr);
+          } else {
+            float dist;
+            uint32_t texel = fetch_texel(L, &s, px, py, &dist);
+            if (dr->kind == KIND_WALL && (texel & 0x8000u)) continue; /* static.frag:21 discard */
+            colour = shade(L, texel & 0xFFu, s.light, dist);
+          }
+          depth[o] = d24;
+          prim[o] = prim_id;
+          out_fb[o] = colour;
+        }
+      }
+    }
+  }
+  if (out_prim) memcpy(out_prim, prim, npx * sizeof(uint32_t));
+  free(depth);
+  free(prim);
+  return 0;
+}
+
+/* Renders a batch of poses with `threads`-way pose parallelism left to the caller (ctypes releases the
+ * GIL); poses: n * (16 modelview + 16 projection + 1 time) floats; lights: n * 256 bytes. */
+int oracle_render_batch(const OracleLevel *L, const float *poses, const uint8_t *lights, int n, int width, int height,
+                        uint32_t kinds_mask, uint8_t *out_fb) {
+  for (int i = 0; i < n; i++) {
+    const float *p = poses + (size_t)i * 33;
+    int rc = oracle_render(L, p, p + 16, p[32], lights + (size_t)i * 256, width, height, kinds_mask,
+                           out_fb + (size_t)i * (size_t)width * (size_t)height, 0);
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -1,0 +1,81 @@
+"""Shared test helpers: synthetic IWAD location, pose generation (numpy f32), PNG dump."""
+import hashlib
+import os
+import struct
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+WAD_PATH = os.path.join(GOLDEN, 'synth.wad')
+META_PATH = os.path.join(ROOT, 'assets', 'meta', 'synth.toml')
+F = np.float32
+
+
+def ensure_wad():
+    """The synthetic IWAD is generated (seeded, deterministic), not committed; its digest is."""
+    if not os.path.exists(WAD_PATH):
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import mkwad
+        wad, _ = mkwad.build_wad(1993)
+        os.makedirs(GOLDEN, exist_ok=True)
+        with open(WAD_PATH, 'wb') as f:
+            f.write(wad)
+    return WAD_PATH
+
+
+def wad_digest():
+    with open(ensure_wad(), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def perspective(fovy_deg, aspect, near, far):
+    """cgmath::perspective (engine/src/projections.rs:93-101), column-major 16 floats."""
+    f = F(1.0) / F(np.tan(np.float64(fovy_deg) * np.pi / 360.0))
+    m = np.zeros((4, 4), np.float32)  # m[c][r]
+    m[0][0] = f / F(aspect)
+    m[1][1] = f
+    m[2][2] = (F(far) + F(near)) / (F(near) - F(far))
+    m[2][3] = F(-1.0)
+    m[3][2] = (F(2.0) * F(far) * F(near)) / (F(near) - F(far))
+    return m.reshape(16)
+
+
+def reference_projection(width, height):
+    """game/src/player.rs:84-89,336-344: fovy 65 deg, aspect*1.2, near 0.01, far 100."""
+    return perspective(65.0, (F(width) / F(height)) * F(1.2), 0.01, 100.0)
+
+
+def view_matrix(eye, yaw, pitch):
+    """inverse(T(eye) * Ry(yaw) * Rx(pitch)), column-major 16 floats (engine/src/renderer.rs:78-87)."""
+    cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], np.float64)
+    rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]], np.float64)
+    r = ry @ rx
+    m = np.eye(4)
+    m[:3, :3] = r.T
+    m[:3, 3] = -(r.T @ np.asarray(eye, np.float64))
+    return m.T.astype(np.float32).reshape(16)  # row-major transpose -> column-major
+
+
+def write_png(path, rgb):
+    h, w, _ = rgb.shape
+    raw = b''.join(b'\0' + rgb[y].tobytes() for y in range(h))
+
+    def chunk(t, d):
+        c = struct.pack('>I', len(d)) + t + d
+        return c + struct.pack('>I', zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    with open(path, 'wb') as f:
+        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 2, 0, 0, 0)) +
+                chunk(b'IDAT', zlib.compress(raw, 6)) + chunk(b'IEND', b''))
+
+
+def fb_to_png(path, fb, playpal):
+    """fb: (h,w) palette indices with row 0 = bottom; playpal: 768 bytes."""
+    pal = np.asarray(playpal, np.uint8).reshape(256, 3)
+    write_png(path, pal[fb[::-1]])
