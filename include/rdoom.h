@@ -1,0 +1,205 @@
+/* rdoom.h -- C ABI of the MI355X pose-batch renderer for Doom WAD levels.
+ *
+ * This is the drop-in boundary.  It replaces what rust-doom hands to
+ * glium/OpenGL; every entry point cites the reference interface it stands in for.  Plain pointers
+ * and sizes only; no C++/torch types; nothing throws across it.
+ *
+ *   loader + builder  (host C++, mirrors `wad` + `game::level`):   rdoom_wad_*, rdoom_built_*
+ *   device renderer   (hand-written HIP, gfx950):                   rdoom_level_*, rdoom_batch_*
+ *
+ * Conventions
+ *   - every function returns rdoom_status (0 = ok, <0 = error); rdoom_last_error() gives a
+ *     thread-local message (reference: Result<T, failchain::BoxedError<ErrorKind>>,
+ *     wad/src/errors.rs:6-19; visitor callbacks are infallible, bad level data is skipped).
+ *   - matrices are column-major float[16], exactly the GLSL uniforms u_modelview / u_projection
+ *     (engine/src/uniforms.rs:273-280).
+ *   - framebuffers are 8-bit palette indices, row 0 = bottom row (glReadPixels order), background 0.
+ *   - a rdoom_level is immutable after create (shareable); a rdoom_batch is single-owner.
+ */
+#ifndef RDOOM_H
+#define RDOOM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t rdoom_status;
+#define RDOOM_OK 0
+#define RDOOM_BAD_ARG (-1)
+#define RDOOM_HIP_ERROR (-2)
+#define RDOOM_OOM (-3)
+#define RDOOM_BAD_LEVEL (-4)
+#define RDOOM_IO (-5)        /* ErrorKind::Io            (wad/src/errors.rs:9-19) */
+#define RDOOM_CORRUPT_WAD (-6)  /* ErrorKind::CorruptWad */
+#define RDOOM_CORRUPT_META (-7) /* ErrorKind::CorruptMetadata */
+
+/* draw kinds, in the reference's per-object attach order (game/src/level.rs:443-496) */
+#define RDOOM_KIND_FLAT 0u
+#define RDOOM_KIND_WALL 1u
+#define RDOOM_KIND_DECOR 2u
+#define RDOOM_KIND_SKY 3u
+#define RDOOM_ALL_KINDS 0xFu
+
+/* game/src/vertex.rs:5-16  StaticVertex (repr(C), 48 bytes) */
+typedef struct rdoom_static_vertex {
+  float a_pos[3];
+  float a_atlas_uv[2];
+  float a_tile_uv[2];
+  float a_tile_size[2];
+  float a_scroll_rate;
+  float a_row_height;
+  uint8_t a_num_frames;
+  uint8_t a_light;
+  uint8_t _pad[2];
+} rdoom_static_vertex;
+
+/* game/src/vertex.rs:30-40  SpriteVertex (repr(C), 44 bytes) */
+typedef struct rdoom_sprite_vertex {
+  float a_pos[3];
+  float a_atlas_uv[2];
+  float a_tile_uv[2];
+  float a_tile_size[2];
+  float a_local_x;
+  uint8_t a_num_frames;
+  uint8_t a_light;
+  uint8_t _pad[2];
+} rdoom_sprite_vertex;
+
+/* One `frame.draw(mesh, indices, program, ...)` of the reference (engine/src/renderer.rs:100-157):
+ * a range of the index array of its vertex buffer.  Draw order == array order. */
+typedef struct rdoom_draw {
+  uint32_t kind;        /* RDOOM_KIND_* */
+  uint32_t object_id;   /* wad::ObjectId (visitor.rs:142-143); 0 = static world */
+  uint32_t first_index; /* into static_indices / decor_indices / sky_indices by kind */
+  uint32_t index_count; /* multiple of 3 (TrianglesList, engine/src/meshes.rs:97-106) */
+} rdoom_draw;
+
+/* Everything Builder::build + GameShaders::load_level give glium for one level
+ * (game/src/level.rs:424-496, game/src/game_shaders.rs:175-453).  Caller owns all arrays;
+ * rdoom_level_create copies them to the device. */
+typedef struct rdoom_level_desc {
+  const rdoom_static_vertex *static_verts;
+  uint32_t n_static_verts;
+  const uint32_t *static_indices;
+  uint32_t n_static_indices;
+  const float *sky_verts; /* SkyVertex: xyz triples (vertex.rs:53-57) */
+  uint32_t n_sky_verts;
+  const uint32_t *sky_indices;
+  uint32_t n_sky_indices;
+  const rdoom_sprite_vertex *decor_verts;
+  uint32_t n_decor_verts;
+  const uint32_t *decor_indices;
+  uint32_t n_decor_indices;
+  const rdoom_draw *draws;
+  uint32_t n_draws;
+  const uint8_t *flat_atlas; /* wad::OpaqueImage (tex.rs:47-50), U8, REPEAT/NEAREST */
+  uint32_t flat_w, flat_h;   /* powers of two (tex.rs:281-286) */
+  const uint16_t *wall_atlas; /* wad::TransparentImage (tex.rs:42-45), U8U8: lo=index, hi>=0x80 transparent */
+  uint32_t wall_w, wall_h;    /* powers of two (tex.rs:183-200) */
+  const uint16_t *decor_atlas;
+  uint32_t decor_w, decor_h;
+  const uint16_t *sky_texture; /* game_shaders.rs:358-387 */
+  uint32_t sky_w, sky_h;
+  float sky_tiled_band_size;
+  const uint8_t *playpal;  /* 768 bytes, palette 0 (kept for RGB expansion by callers) */
+  const uint8_t *colormap; /* 32*256 bytes: rows of build_palette_texture(0,0,32) before the PLAYPAL map (tex.rs:137-166) */
+} rdoom_level_desc;
+
+/* Per-frame uniforms (engine/src/renderer.rs:78-132, game/src/game_shaders.rs:84-92). */
+typedef struct rdoom_pose {
+  float modelview[16];
+  float projection[16];
+  float time; /* u_time, seconds */
+  float _pad;
+} rdoom_pose;
+
+typedef struct rdoom_level rdoom_level;
+typedef struct rdoom_batch rdoom_batch;
+typedef struct rdoom_wad rdoom_wad;
+typedef struct rdoom_built rdoom_built;
+
+/* per-kernel GPU times of the last rdoom_batch_render, from hipEvents on the render stream */
+typedef struct rdoom_timings {
+  float setup_ms, raster_ms, fragment_ms, total_ms;
+  uint64_t pixels; /* n_poses * width * height of that render */
+  uint64_t visible_triangles;
+} rdoom_timings;
+
+/* counters logged by the reference at level build (game/src/level.rs:384-422) */
+typedef struct rdoom_counters {
+  uint32_t num_wall_quads, num_floor_polys, num_ceil_polys, num_sky_wall_quads, num_sky_floor_polys,
+      num_sky_ceil_polys, num_decors, num_static_tris, num_sky_tris, num_sprite_tris, num_objects, num_lights;
+} rdoom_counters;
+
+const char *rdoom_last_error(void);
+
+/* ---- devices ------------------------------------------------------------------------------ */
+rdoom_status rdoom_device_count(int32_t *out_count);
+rdoom_status rdoom_set_device(int32_t device);
+
+/* ---- device renderer: replaces engine Meshes/Uniforms uploads + Renderer::update ----------- */
+/* replaces VertexBuffer::immutable / IndexBuffer::persistent / Texture2d::new uploads
+ * (engine/src/meshes.rs:126-201, engine/src/uniforms.rs:146-221) */
+rdoom_status rdoom_level_create(const rdoom_level_desc *desc, rdoom_level **out_level);
+void rdoom_level_destroy(rdoom_level *level);
+
+/* allocates the device scratch for up to max_poses frames of width x height (width % 4 == 0) */
+rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32_t height, uint32_t max_poses,
+                                rdoom_batch **out_batch);
+void rdoom_batch_destroy(rdoom_batch *batch);
+
+/* replaces the frame.draw loop of Renderer::update (engine/src/renderer.rs:98-157) for n_poses
+ * frames at once.  lights: n_poses tables of 256 bytes (Lights::fill_buffer_at, game/src/lights.rs:26-30)
+ * spaced lights_stride bytes apart (0 = one shared table).  kinds_mask selects draw kinds.
+ * Asynchronous on `stream` (a hipStream_t, may be NULL); results stay on the device. */
+rdoom_status rdoom_batch_render(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream);
+/* same, with per-kernel hipEvent timing (synchronises the stream) */
+rdoom_status rdoom_batch_render_timed(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                      uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
+                                      rdoom_timings *out);
+/* device pointer to the n_poses*height*width palette-index framebuffers of the last render */
+rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **out_device_ptr);
+/* glReadPixels analogue: synchronises, copies frames [first, first+count) to host memory */
+rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *batch, uint32_t first, uint32_t count, uint8_t *host_out);
+/* winning primitive id per pixel (global triangle index in draw order, 0xFFFFFFFF = none) */
+rdoom_status rdoom_batch_read_primitive_ids(rdoom_batch *batch, uint32_t first, uint32_t count, uint32_t *host_out);
+
+/* ---- loader + builder: the `wad` crate and `game::level` static-geometry builder ----------- */
+/* Archive::open (wad/src/archive.rs:36-60) + TextureDirectory::from_archive (wad/src/tex.rs:53-107) */
+rdoom_status rdoom_wad_open(const char *wad_path, const char *metadata_path, rdoom_wad **out_wad);
+void rdoom_wad_close(rdoom_wad *wad);
+rdoom_status rdoom_wad_num_levels(const rdoom_wad *wad, uint32_t *out);           /* Archive::num_levels */
+rdoom_status rdoom_wad_level_name(const rdoom_wad *wad, uint32_t index, char out_name[9]); /* WadSystem::level_name */
+/* WadName::from_bytes (wad/src/name.rs:41-75); out = 8 bytes */
+rdoom_status rdoom_wad_name_from_bytes(const uint8_t *bytes, uint32_t len, uint8_t out[8]);
+
+/* WadSystem::create's level half + GameShaders::load_level + Builder::build
+ * (game/src/wad_system.rs:72-113, game/src/game_shaders.rs:175-387, game/src/level.rs:330-496).
+ * use_gpu_tessellation != 0 runs the SSECTOR->polygon / SEG->quad kernels on the current device
+ * (results are identical to the host walk). */
+rdoom_status rdoom_wad_build_level(const rdoom_wad *wad, uint32_t level_index, int32_t use_gpu_tessellation,
+                                   rdoom_built **out_built);
+void rdoom_built_destroy(rdoom_built *built);
+/* borrowed pointers into `built`, valid until rdoom_built_destroy */
+rdoom_status rdoom_built_desc(const rdoom_built *built, rdoom_level_desc *out_desc);
+rdoom_status rdoom_built_counters(const rdoom_built *built, rdoom_counters *out);
+/* Lights::fill_buffer_at (game/src/lights.rs:26-30) */
+rdoom_status rdoom_built_lights_at(const rdoom_built *built, float time, uint8_t out_lights[256]);
+/* Builder::visit_marker start pose (game/src/level.rs:757-762) */
+rdoom_status rdoom_built_start(const rdoom_built *built, float out_pos[3], float *out_yaw);
+/* bounds of the sub-sector floor polygons, for pose generators: n polygons, centroid xz + floor y */
+rdoom_status rdoom_built_floor_centroids(const rdoom_built *built, const float **out_xyz, uint32_t *out_n);
+
+/* Camera of the reference: view = inverse(T(eye) * Ry(yaw) * Rx(pitch)),
+ * projection = perspective(65 deg, (w/h)*1.2, 0.01, 100) (game/src/player.rs:84-89, 325-345;
+ * engine/src/projections.rs:93-101; engine/src/renderer.rs:78-87). */
+rdoom_status rdoom_pose_look(const float eye[3], float yaw, float pitch, uint32_t width, uint32_t height, float time,
+                             rdoom_pose *out_pose);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDOOM_H */

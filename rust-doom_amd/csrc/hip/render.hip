@@ -1,0 +1,756 @@
+// Pose-batch renderer for gfx950 (MI355X): per-pose triangle setup, tiled rasteriser with an LDS
+// triangle queue and register-resident depth/coverage, and the PLAYPAL/COLORMAP fragment kernel.
+//
+// Replaces the reference's GL draw path: assets/shaders/static.{vert,frag}, sky.{vert,frag} and the
+// fixed-function state of engine/src/renderer.rs:49-57 + engine/src/window.rs:12,40-44.  The
+// arithmetic every kernel must reproduce is specified in DESIGN.md "Raster arithmetic" (steps
+// V1.., S1.., R1.., F1..); operation order below follows that text, not the oracle's source.
+// Built with -ffp-contract=off: a*b+c is never fused unless written as fmaf.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "../common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int TILE_W = 32, TILE_H = 32;  // one 256-thread workgroup, 4 pixels (a 4x1 strip) per lane
+constexpr int QCAP = 256;
+
+// ---- level-constant triangle record (built once per level on the host) -----------------------
+struct alignas(16) LevelTri {  // 96 bytes
+  float pos[9];
+  float uv[6];
+  float scroll[3];
+  float atlas_u, atlas_v, size_x, size_y, row_height;
+  uint32_t packed;  // num_frames | light << 8 | kind << 16 | masked << 18
+};
+static_assert(sizeof(LevelTri) == 96, "LevelTri layout");
+
+struct alignas(16) PoseConst {  // 336 bytes
+  float pm[16];                 // projection * modelview (V1)
+  float time, vr0, vr1, pad;
+  uint8_t lights[256];
+};
+static_assert(sizeof(PoseConst) == 336, "PoseConst layout");
+
+// ---- per (pose, visible triangle) records -----------------------------------------------------
+struct alignas(16) RasterRec {  // 80 bytes
+  float e[9];                   // edge functions A,B,C x3
+  float zp[3];                  // window-depth plane
+  float wp[3];                  // 1/w plane
+  uint32_t bb0, bb1;            // x0 | y0 << 16, x1 | y1 << 16 (inclusive)
+  uint32_t flags;               // prim id (24 bits) | tl << 24 | kind << 27 | masked << 29
+  uint32_t pad[2];
+};
+static_assert(sizeof(RasterRec) == 80, "RasterRec layout");
+
+struct alignas(16) ShadeRec {  // 64 bytes
+  float wp[3];
+  float up[3];
+  float vp[3];
+  float atlas_u, atlas_v, size_x, size_y, light;
+  uint32_t kind;
+  uint32_t pad;
+};
+static_assert(sizeof(ShadeRec) == 64, "ShadeRec layout");
+
+struct DeviceLevelView {
+  const LevelTri *tris;
+  uint32_t ntri;
+  const uint8_t *flat_atlas;
+  uint32_t flat_w, flat_h;
+  const uint16_t *wall_atlas;
+  uint32_t wall_w, wall_h;
+  const uint16_t *sky_tex;
+  uint32_t sky_w, sky_h;
+  float sky_band;
+  const uint8_t *colormap;
+};
+
+__device__ __forceinline__ float plane3(const float *p, float px, float py) {
+  return fmaf(p[0], px, fmaf(p[1], py, p[2]));
+}
+__device__ __forceinline__ float dop(float a, float b, float c, float d) {
+  float p = a * b;
+  float q = c * d;
+  return p - q;
+}
+__device__ __forceinline__ float glsl_mod(float x, float y) { return x - y * floorf(x / y); }
+
+// =================================================================================================
+// Kernel 1: vertex stage + triangle setup (V2..V5, S1..S6), one thread per (pose, triangle).
+// Visible triangles are appended per pose with one wave-aggregated atomic per wavefront.
+// =================================================================================================
+__global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
+                                                    int width, int height, uint32_t kinds_mask,
+                                                    RasterRec *__restrict__ rrec, ShadeRec *__restrict__ srec,
+                                                    uint32_t *__restrict__ counts, uint32_t cap) {
+  const uint32_t pose = blockIdx.y;
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const PoseConst &pc = poses[pose];
+  bool ok = t < lv.ntri;
+  RasterRec rr;
+  ShadeRec sr;
+  if (ok) {
+    const LevelTri tri = lv.tris[t];
+    const uint32_t kind = (tri.packed >> 16) & 3u;
+    ok = ((kinds_mask >> kind) & 1u) && kind != RDOOM_KIND_DECOR;
+    if (ok) {
+      float clip[3][4], u[3], v[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const float x = tri.pos[3 * i], y = tri.pos[3 * i + 1], z = tri.pos[3 * i + 2];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          clip[i][r] = fmaf(pc.pm[8 + r], z, fmaf(pc.pm[4 + r], y, fmaf(pc.pm[r], x, pc.pm[12 + r])));
+        u[i] = tri.uv[2 * i] + pc.time * tri.scroll[i];
+        v[i] = tri.uv[2 * i + 1];
+      }
+      // flat varyings (provoking vertex data were folded into LevelTri on the host)
+      const uint32_t nframes = tri.packed & 0xFFu;
+      float au = tri.atlas_u, av = tri.atlas_v;
+      if (nframes != 1u && kind != RDOOM_KIND_SKY) {
+        const float aw = kind == RDOOM_KIND_FLAT ? (float)lv.flat_w : (float)lv.wall_w;
+        const float anim_fps = 8.0f / 35.0f;
+        float fi = pc.time / anim_fps;
+        fi = floorf(glsl_mod(fi, (float)nframes));
+        float atlas_u = tri.atlas_u + fi * tri.size_x;
+        const float rows_down = ceilf((atlas_u + tri.size_x) / aw) - 1.0f;
+        atlas_u = atlas_u + glsl_mod(aw - tri.atlas_u, tri.size_x) * rows_down;
+        au = atlas_u;
+        av = tri.atlas_v + rows_down * tri.row_height;
+      }
+      ok = !(clip[0][3] <= 0.0f && clip[1][3] <= 0.0f && clip[2][3] <= 0.0f);
+      if (ok) {
+        const float hw = 0.5f * (float)width, hh = 0.5f * (float)height;
+        float xw[3], yw[3], w[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          xw[i] = (clip[i][0] + clip[i][3]) * hw;
+          yw[i] = (clip[i][1] + clip[i][3]) * hh;
+          w[i] = clip[i][3];
+        }
+        uint32_t tl = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const int j = (i + 1) % 3, k = (i + 2) % 3;
+          const float A = dop(yw[j], w[k], yw[k], w[j]);
+          const float B = dop(xw[k], w[j], xw[j], w[k]);
+          const float C = dop(xw[j], yw[k], xw[k], yw[j]);
+          rr.e[3 * i] = A;
+          rr.e[3 * i + 1] = B;
+          rr.e[3 * i + 2] = C;
+          if ((A > 0.0f) || (A == 0.0f && B > 0.0f)) tl |= 1u << i;
+        }
+        const float det = fmaf(w[0], rr.e[2], fmaf(yw[0], rr.e[1], xw[0] * rr.e[0]));
+        ok = det > 0.0f;
+        if (ok) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const float e0 = rr.e[c], e1 = rr.e[3 + c], e2 = rr.e[6 + c];
+            const float nz = fmaf(clip[2][2], e2, fmaf(clip[1][2], e1, clip[0][2] * e0));
+            const float n1 = (e0 + e1) + e2;
+            const float nu = fmaf(u[2], e2, fmaf(u[1], e1, u[0] * e0));
+            const float nv = fmaf(v[2], e2, fmaf(v[1], e1, v[0] * e0));
+            rr.zp[c] = 0.5f * (nz / det);
+            rr.wp[c] = n1 / det;
+            sr.up[c] = nu / det;
+            sr.vp[c] = nv / det;
+          }
+          rr.zp[2] = rr.zp[2] + 0.5f;
+          int x0 = 0, y0 = 0, x1 = width - 1, y1 = height - 1;
+          const float wmin = fminf(w[0], fminf(w[1], w[2]));
+          if (wmin >= 1e-5f) {
+            float sx[3], sy[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+              sx[i] = xw[i] / w[i];
+              sy[i] = yw[i] / w[i];
+            }
+            const float fx0 = floorf(fminf(sx[0], fminf(sx[1], sx[2]))) - 1.0f;
+            const float fx1 = ceilf(fmaxf(sx[0], fmaxf(sx[1], sx[2]))) + 1.0f;
+            const float fy0 = floorf(fminf(sy[0], fminf(sy[1], sy[2]))) - 1.0f;
+            const float fy1 = ceilf(fmaxf(sy[0], fmaxf(sy[1], sy[2]))) + 1.0f;
+            ok = fx0 <= (float)(width - 1) && fx1 >= 0.0f && fy0 <= (float)(height - 1) && fy1 >= 0.0f;
+            if (ok) {
+              x0 = (int)fmaxf(fx0, 0.0f);
+              y0 = (int)fmaxf(fy0, 0.0f);
+              x1 = (int)fminf(fx1, (float)(width - 1));
+              y1 = (int)fminf(fy1, (float)(height - 1));
+            }
+          }
+          rr.bb0 = (uint32_t)x0 | ((uint32_t)y0 << 16);
+          rr.bb1 = (uint32_t)x1 | ((uint32_t)y1 << 16);
+          const uint32_t masked = (tri.packed >> 18) & 1u;
+          rr.flags = (t & 0xFFFFFFu) | (tl << 24) | (kind << 27) | (masked << 29);
+          rr.pad[0] = rr.pad[1] = 0;
+          sr.wp[0] = rr.wp[0];
+          sr.wp[1] = rr.wp[1];
+          sr.wp[2] = rr.wp[2];
+          sr.atlas_u = au;
+          sr.atlas_v = av;
+          sr.size_x = tri.size_x;
+          sr.size_y = tri.size_y;
+          sr.light = (float)pc.lights[(tri.packed >> 8) & 0xFFu] / 255.0f;
+          sr.kind = kind;
+          sr.pad = t;
+        }
+      }
+    }
+  }
+  // wave-aggregated append: one atomic per wavefront (64 lanes)
+  const unsigned long long mask = __ballot(ok);
+  if (mask == 0ull) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(&counts[pose], (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (ok) {
+    const size_t o = (size_t)pose * cap + base + rank;
+    rrec[o] = rr;
+    srec[o] = sr;
+  }
+}
+
+// texel fetch shared by the alpha test (R6) and the fragment stage (F1..F3)
+__device__ __forceinline__ uint32_t fetch_texel(const DeviceLevelView &lv, const ShadeRec &s, float px, float py,
+                                                float &dist) {
+  const float rw = plane3(s.wp, px, py);
+  const float w = 1.0f / rw;
+  const float tu = plane3(s.up, px, py) * w;
+  const float tv = plane3(s.vp, px, py) * w;
+  dist = w;
+  const float uvx = glsl_mod(tu, s.size_x) + s.atlas_u;
+  const float uvy = glsl_mod(tv, s.size_y) + s.atlas_v;
+  const int ix = (int)floorf(uvx), iy = (int)floorf(uvy);
+  if (s.kind == RDOOM_KIND_FLAT)
+    return lv.flat_atlas[(size_t)(iy & (int)(lv.flat_h - 1)) * lv.flat_w + (size_t)(ix & (int)(lv.flat_w - 1))];
+  return lv.wall_atlas[(size_t)(iy & (int)(lv.wall_h - 1)) * lv.wall_w + (size_t)(ix & (int)(lv.wall_w - 1))];
+}
+
+// =================================================================================================
+// Kernel 2: tiled rasteriser.  One 256-thread workgroup per (pose, 32x32 tile).  Lanes first act
+// as triangles (bbox-vs-tile test, survivors are staged into an LDS queue), then as pixels: every
+// lane owns a 4x1 strip and keeps its depth / winner in registers while the queue is replayed
+// from LDS (broadcast reads).  Winner = lexicographic min of (d24, primitive id): order-free.
+// blockIdx -> (pose, tile) keeps all tiles of a pose on one XCD (b % 8) so its records stay in
+// that XCD's L2.
+// =================================================================================================
+__global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const RasterRec *__restrict__ rrec,
+                                                     const ShadeRec *__restrict__ srec,
+                                                     const uint32_t *__restrict__ counts, uint32_t cap,
+                                                     uint32_t n_poses, int width, int height, int tiles_x,
+                                                     int tiles_y, uint32_t *__restrict__ vis,
+                                                     uint32_t *__restrict__ prim_out) {
+  __shared__ RasterRec q[QCAP];
+  __shared__ uint32_t qidx[QCAP];
+  __shared__ uint32_t qn;
+  const uint32_t b = blockIdx.x;
+  const uint32_t T = (uint32_t)(tiles_x * tiles_y);
+  const uint32_t g = b >> 3;
+  const uint32_t pose = (g / T) * 8u + (b & 7u);
+  const uint32_t tile = g % T;
+  if (pose >= n_poses) return;
+  const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE_W, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE_H;
+  const int tid = threadIdx.x;
+  const int sx = tx0 + (tid & 7) * 4, sy = ty0 + (tid >> 3);
+  const float py = (float)sy + 0.5f;
+  uint32_t best_d[4], best_p[4], best_r[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    best_d[k] = NONE;
+    best_p[k] = NONE;
+    best_r[k] = NONE;
+  }
+  if (tid == 0) qn = 0;
+  __syncthreads();
+  const uint32_t count = counts[pose];
+  const RasterRec *prr = rrec + (size_t)pose * cap;
+  const ShadeRec *psr = srec + (size_t)pose * cap;
+  for (uint32_t base = 0; base < count; base += 256u) {
+    const uint32_t i = base + (uint32_t)tid;
+    if (i < count) {
+      const uint32_t bb0 = prr[i].bb0, bb1 = prr[i].bb1;
+      const int x0 = (int)(bb0 & 0xFFFFu), y0 = (int)(bb0 >> 16), x1 = (int)(bb1 & 0xFFFFu), y1 = (int)(bb1 >> 16);
+      if (x0 <= tx0 + TILE_W - 1 && x1 >= tx0 && y0 <= ty0 + TILE_H - 1 && y1 >= ty0) {
+        const uint32_t slot = atomicAdd(&qn, 1u);
+        q[slot] = prr[i];
+        qidx[slot] = i;
+      }
+    }
+    __syncthreads();
+    const uint32_t n = qn;
+    for (uint32_t j = 0; j < n; j++) {
+      const RasterRec &r = q[j];
+      const int x0 = (int)(r.bb0 & 0xFFFFu), y0 = (int)(r.bb0 >> 16), x1 = (int)(r.bb1 & 0xFFFFu),
+                y1 = (int)(r.bb1 >> 16);
+      if (sy < y0 || sy > y1 || sx + 3 < x0 || sx > x1) continue;
+      const uint32_t flags = r.flags;
+      const uint32_t prim = flags & 0xFFFFFFu;
+      const uint32_t ridx = qidx[j];
+      const float e0a = r.e[0], e0b = r.e[1], e0c = r.e[2], e1a = r.e[3], e1b = r.e[4], e1c = r.e[5], e2a = r.e[6],
+                  e2b = r.e[7], e2c = r.e[8];
+      const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
+      const float tz = fmaf(r.zp[1], py, r.zp[2]), tw = fmaf(r.wp[1], py, r.wp[2]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int ix = sx + k;
+        const float px = (float)ix + 0.5f;
+        const float e0 = fmaf(e0a, px, t0), e1 = fmaf(e1a, px, t1), e2 = fmaf(e2a, px, t2);
+        const bool in0 = (e0 > 0.0f) || (e0 == 0.0f && (flags & (1u << 24)) != 0u);
+        const bool in1 = (e1 > 0.0f) || (e1 == 0.0f && (flags & (1u << 25)) != 0u);
+        const bool in2 = (e2 > 0.0f) || (e2 == 0.0f && (flags & (1u << 26)) != 0u);
+        const float zw = fmaf(r.zp[0], px, tz);
+        const float rw = fmaf(r.wp[0], px, tw);
+        const uint32_t d24 = (uint32_t)fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f);
+        bool pass = ix >= x0 && ix <= x1 && in0 && in1 && in2 && zw >= 0.0f && zw <= 1.0f && rw > 0.0f &&
+                    (d24 < best_d[k] || (d24 == best_d[k] && prim < best_p[k]));
+        if (pass && (flags & (1u << 29)) != 0u) {  // masked wall texture: alpha test before the depth write
+          float dist;
+          const uint32_t texel = fetch_texel(lv, psr[ridx], px, py, dist);
+          pass = (texel & 0x8000u) == 0u;
+        }
+        if (pass) {
+          best_d[k] = d24;
+          best_p[k] = prim;
+          best_r[k] = ridx;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) qn = 0;
+    __syncthreads();
+  }
+  if (sy < height && sx < width) {
+    const size_t o = ((size_t)pose * (size_t)height + (size_t)sy) * (size_t)width + (size_t)sx;
+    *reinterpret_cast<uint4 *>(vis + o) = make_uint4(best_r[0], best_r[1], best_r[2], best_r[3]);
+    if (prim_out) *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(best_p[0], best_p[1], best_p[2], best_p[3]);
+  }
+}
+
+// =================================================================================================
+// Kernel 3: fragment kernel (F1..F6): visibility record -> atlas texel -> COLORMAP row -> 8-bit
+// palette index.  One lane per 4 horizontally adjacent pixels: one 16-byte visibility load, one
+// 4-byte packed store.  COLORMAP (8 KiB) is staged in LDS once per workgroup; a workgroup walks
+// CHUNK consecutive 1024-pixel slabs so that staging is amortised.
+// =================================================================================================
+constexpr int FRAG_CHUNK = 16;
+
+__device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const uint8_t *cmap, float px, float py,
+                                              int width, int height, float vr0, float vr1) {
+  const float ndc_x = px / (0.5f * (float)width) - 1.0f;
+  const float ndc_y = py / (0.5f * (float)height) - 1.0f;
+  float uvx = ndc_x;
+  float uvy = -ndc_y;
+  uvx = uvx - 4.0f * vr0 / 3.14159265358f;
+  uvy = (uvy + 1.0f) + vr1;
+  const float band = lv.sky_band;
+  if (uvy < 0.0f) {
+    uvy = fabsf(glsl_mod(-uvy + band, band * 2.0f) - band);
+  } else if (uvy >= 2.0f) {
+    uvy = fabsf(glsl_mod((uvy - 2.0f) + band, band * 2.0f) - band);
+  } else if (uvy >= 1.0f) {
+    uvy = 1.0f - uvy;
+  }
+  const float fx = uvx - floorf(uvx), fy = uvy - floorf(uvy);
+  int ix = (int)floorf(fx * (float)lv.sky_w), iy = (int)floorf(fy * (float)lv.sky_h);
+  if (ix >= (int)lv.sky_w) ix = (int)lv.sky_w - 1;
+  if (iy >= (int)lv.sky_h) iy = (int)lv.sky_h - 1;
+  const uint32_t texel = lv.sky_tex[(size_t)iy * lv.sky_w + (size_t)ix];
+  return cmap[texel & 0xFFu];
+}
+
+__global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const ShadeRec *__restrict__ srec,
+                                                       uint32_t cap, const PoseConst *__restrict__ poses,
+                                                       const uint32_t *__restrict__ vis, uint64_t n_quads,
+                                                       int width, int height, uint8_t *__restrict__ fb) {
+  __shared__ uint8_t cmap[32 * 256];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(lv.colormap);
+    uint4 *dst = reinterpret_cast<uint4 *>(cmap);
+    dst[threadIdx.x] = src[threadIdx.x];
+    dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+  }
+  __syncthreads();
+  const uint32_t quads_per_row = (uint32_t)width >> 2;
+  const uint64_t quads_per_pose = (uint64_t)quads_per_row * (uint64_t)height;
+  for (int it = 0; it < FRAG_CHUNK; it++) {
+    const uint64_t qi = ((uint64_t)blockIdx.x * FRAG_CHUNK + (uint64_t)it) * 256ull + threadIdx.x;
+    if (qi >= n_quads) break;
+    const uint32_t pose = (uint32_t)(qi / quads_per_pose);
+    const uint32_t rem = (uint32_t)(qi - (uint64_t)pose * quads_per_pose);
+    const uint32_t row = rem / quads_per_row, qx = rem - row * quads_per_row;
+    const uint4 ids = reinterpret_cast<const uint4 *>(vis)[qi];
+    const uint32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
+    const float py = (float)row + 0.5f;
+    const ShadeRec *psr = srec + (size_t)pose * cap;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t c = 0;
+      if (id[k] != NONE) {
+        const float px = (float)(qx * 4u + (uint32_t)k) + 0.5f;
+        const ShadeRec s = psr[id[k]];
+        if (s.kind == RDOOM_KIND_SKY) {
+          c = shade_sky(lv, cmap, px, py, width, height, poses[pose].vr0, poses[pose].vr1);
+        } else {
+          float dist;
+          const uint32_t texel = fetch_texel(lv, s, px, py, dist);
+          const float dist_term = fminf(1.0f, 1.0f - 0.9f / (dist + 0.9f));
+          const float light = s.light * 2.0f - dist_term;
+          const float t = (1.0f - light) * 32.0f;
+          const int rowc = t < 0.0f ? 0 : (t >= 32.0f ? 31 : (int)floorf(t));
+          c = cmap[rowc * 256 + (int)(texel & 0xFFu)];
+        }
+      }
+      out |= c << (8 * k);
+    }
+    reinterpret_cast<uint32_t *>(fb)[qi] = out;
+  }
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+#define HIP_TRY(expr)                                                                                     \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess)                                                                                 \
+      return rdoom::fail(_e == hipErrorOutOfMemory ? RDOOM_OOM : RDOOM_HIP_ERROR, "%s failed: %s", #expr, \
+                         hipGetErrorString(_e));                                                          \
+  } while (0)
+
+bool is_pow2(uint32_t x) { return x != 0 && (x & (x - 1)) == 0; }
+
+}  // namespace
+
+struct rdoom_level {
+  int device = 0;
+  DeviceLevelView view{};
+  void *d_tris = nullptr, *d_flat = nullptr, *d_wall = nullptr, *d_sky = nullptr, *d_cmap = nullptr;
+  uint32_t ntri = 0;
+};
+
+struct rdoom_batch {
+  const rdoom_level *level = nullptr;
+  uint32_t width = 0, height = 0, max_poses = 0, cap = 0, last_n = 0;
+  PoseConst *d_poses = nullptr;
+  RasterRec *d_rrec = nullptr;
+  ShadeRec *d_srec = nullptr;
+  uint32_t *d_counts = nullptr, *d_vis = nullptr, *d_prim = nullptr;
+  uint8_t *d_fb = nullptr;
+  PoseConst *h_poses = nullptr;  // pinned staging for the per-pose constants
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_copy = nullptr;  // H2D of h_poses finished: staging may be rewritten
+  bool want_prim = false;
+};
+
+extern "C" {
+
+rdoom_status rdoom_device_count(int32_t *out_count) {
+  if (!out_count) return rdoom::fail(RDOOM_BAD_ARG, "out_count is null");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  *out_count = n;
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_set_device(int32_t device) {
+  HIP_TRY(hipSetDevice(device));
+  return RDOOM_OK;
+}
+
+void rdoom_level_destroy(rdoom_level *level) {
+  if (!level) return;
+  for (void *p : {level->d_tris, level->d_flat, level->d_wall, level->d_sky, level->d_cmap})
+    if (p) (void)hipFree(p);
+  delete level;
+}
+
+rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_level) {
+  if (!d || !out_level) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out_level = nullptr;
+  if (!d->colormap) return rdoom::fail(RDOOM_BAD_ARG, "colormap is null");
+  if ((d->flat_w | d->flat_h) && !(is_pow2(d->flat_w) && is_pow2(d->flat_h)))
+    return rdoom::fail(RDOOM_BAD_ARG, "flat atlas %ux%u is not a power of two", d->flat_w, d->flat_h);
+  if ((d->wall_w | d->wall_h) && !(is_pow2(d->wall_w) && is_pow2(d->wall_h)))
+    return rdoom::fail(RDOOM_BAD_ARG, "wall atlas %ux%u is not a power of two", d->wall_w, d->wall_h);
+  // flatten the draws into one primitive list in draw order (primitive id == position)
+  std::vector<LevelTri> tris;
+  std::map<std::tuple<float, float, float, float, uint32_t, float>, bool> masked_cache;
+  auto region_masked = [&](const rdoom_static_vertex &v) -> bool {
+    auto key = std::make_tuple(v.a_atlas_uv[0], v.a_atlas_uv[1], v.a_tile_size[0], v.a_tile_size[1],
+                               (uint32_t)v.a_num_frames, v.a_row_height);
+    auto it = masked_cache.find(key);
+    if (it != masked_cache.end()) return it->second;
+    bool m = false;
+    const double W = d->wall_w, au = v.a_atlas_uv[0], av = v.a_atlas_uv[1], sx = v.a_tile_size[0],
+                 sy = v.a_tile_size[1];
+    const uint32_t nf = v.a_num_frames == 0 ? 1u : v.a_num_frames;
+    for (uint32_t f = 0; f < nf && !m; f++) {
+      double u0 = au + f * sx;
+      double rows = std::ceil((u0 + sx) / W) - 1.0;
+      if (nf == 1) rows = 0;
+      double md = sx > 0 ? (W - au) - sx * std::floor((W - au) / sx) : 0;
+      u0 += md * rows;
+      double v0 = av + rows * v.a_row_height;
+      // one texel of margin on every side: the float mod may land one texel outside the rectangle
+      for (long y = (long)std::floor(v0) - 1; y <= (long)std::ceil(v0 + sy) && !m; y++)
+        for (long x = (long)std::floor(u0) - 1; x <= (long)std::ceil(u0 + sx); x++) {
+          const uint32_t xx = (uint32_t)x & (d->wall_w - 1), yy = (uint32_t)y & (d->wall_h - 1);
+          if (d->wall_atlas[(size_t)yy * d->wall_w + xx] & 0x8000u) {
+            m = true;
+            break;
+          }
+        }
+    }
+    masked_cache[key] = m;
+    return m;
+  };
+  for (uint32_t di = 0; di < d->n_draws; di++) {
+    const rdoom_draw &dr = d->draws[di];
+    if (dr.index_count % 3 != 0) return rdoom::fail(RDOOM_BAD_ARG, "draw %u: index_count not a multiple of 3", di);
+    for (uint32_t t = 0; t < dr.index_count / 3; t++) {
+      LevelTri lt;
+      std::memset(&lt, 0, sizeof lt);
+      lt.packed = 1u | (dr.kind << 16);
+      if (dr.kind == RDOOM_KIND_FLAT || dr.kind == RDOOM_KIND_WALL) {
+        if ((uint64_t)dr.first_index + dr.index_count > d->n_static_indices)
+          return rdoom::fail(RDOOM_BAD_ARG, "draw %u: static index range out of bounds", di);
+        const rdoom_static_vertex *vv[3];
+        for (int i = 0; i < 3; i++) {
+          const uint32_t idx = d->static_indices[dr.first_index + 3 * t + i];
+          if (idx >= d->n_static_verts) return rdoom::fail(RDOOM_BAD_ARG, "draw %u: vertex index out of bounds", di);
+          vv[i] = &d->static_verts[idx];
+          std::memcpy(&lt.pos[3 * i], vv[i]->a_pos, 12);
+          lt.uv[2 * i] = vv[i]->a_tile_uv[0];
+          lt.uv[2 * i + 1] = vv[i]->a_tile_uv[1];
+          lt.scroll[i] = vv[i]->a_scroll_rate;
+        }
+        const rdoom_static_vertex &pv = *vv[2];  // flat varyings: provoking (last) vertex
+        lt.atlas_u = pv.a_atlas_uv[0];
+        lt.atlas_v = pv.a_atlas_uv[1];
+        lt.size_x = pv.a_tile_size[0];
+        lt.size_y = pv.a_tile_size[1];
+        lt.row_height = pv.a_row_height;
+        bool masked = false;
+        if (dr.kind == RDOOM_KIND_WALL) {
+          if (!d->wall_atlas) return rdoom::fail(RDOOM_BAD_ARG, "wall draw without a wall atlas");
+          masked = region_masked(pv);
+        } else if (!d->flat_atlas) {
+          return rdoom::fail(RDOOM_BAD_ARG, "flat draw without a flat atlas");
+        }
+        lt.packed = (uint32_t)pv.a_num_frames | ((uint32_t)pv.a_light << 8) | (dr.kind << 16) |
+                    ((masked ? 1u : 0u) << 18);
+      } else if (dr.kind == RDOOM_KIND_SKY) {
+        if ((uint64_t)dr.first_index + dr.index_count > d->n_sky_indices)
+          return rdoom::fail(RDOOM_BAD_ARG, "draw %u: sky index range out of bounds", di);
+        for (int i = 0; i < 3; i++) {
+          const uint32_t idx = d->sky_indices[dr.first_index + 3 * t + i];
+          if (idx >= d->n_sky_verts) return rdoom::fail(RDOOM_BAD_ARG, "draw %u: sky vertex out of bounds", di);
+          std::memcpy(&lt.pos[3 * i], &d->sky_verts[3 * idx], 12);
+        }
+      } else if (dr.kind != RDOOM_KIND_DECOR) {
+        return rdoom::fail(RDOOM_BAD_ARG, "draw %u: unknown kind %u", di, dr.kind);
+      }
+      tris.push_back(lt);
+    }
+  }
+  if (tris.size() >= (1u << 24)) return rdoom::fail(RDOOM_BAD_LEVEL, "too many triangles (%zu)", tris.size());
+  rdoom_level *lv = new rdoom_level;
+  (void)hipGetDevice(&lv->device);
+  lv->ntri = (uint32_t)tris.size();
+  auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+    if (bytes == 0 || !src) {
+      *dst = nullptr;
+      return hipSuccess;
+    }
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  hipError_t e = upload(&lv->d_tris, tris.data(), tris.size() * sizeof(LevelTri));
+  if (e == hipSuccess) e = upload(&lv->d_flat, d->flat_atlas, (size_t)d->flat_w * d->flat_h);
+  if (e == hipSuccess) e = upload(&lv->d_wall, d->wall_atlas, (size_t)d->wall_w * d->wall_h * 2);
+  if (e == hipSuccess) e = upload(&lv->d_sky, d->sky_texture, (size_t)d->sky_w * d->sky_h * 2);
+  if (e == hipSuccess) e = upload(&lv->d_cmap, d->colormap, 32 * 256);
+  if (e != hipSuccess) {
+    rdoom_level_destroy(lv);
+    return rdoom::fail(e == hipErrorOutOfMemory ? RDOOM_OOM : RDOOM_HIP_ERROR, "level upload failed: %s",
+                       hipGetErrorString(e));
+  }
+  lv->view.tris = (const LevelTri *)lv->d_tris;
+  lv->view.ntri = lv->ntri;
+  lv->view.flat_atlas = (const uint8_t *)lv->d_flat;
+  lv->view.flat_w = d->flat_w;
+  lv->view.flat_h = d->flat_h;
+  lv->view.wall_atlas = (const uint16_t *)lv->d_wall;
+  lv->view.wall_w = d->wall_w;
+  lv->view.wall_h = d->wall_h;
+  lv->view.sky_tex = (const uint16_t *)lv->d_sky;
+  lv->view.sky_w = lv->d_sky ? d->sky_w : 0;
+  lv->view.sky_h = lv->d_sky ? d->sky_h : 0;
+  lv->view.sky_band = d->sky_tiled_band_size;
+  lv->view.colormap = (const uint8_t *)lv->d_cmap;
+  *out_level = lv;
+  return RDOOM_OK;
+}
+
+void rdoom_batch_destroy(rdoom_batch *b) {
+  if (!b) return;
+  for (void *p : {(void *)b->d_poses, (void *)b->d_rrec, (void *)b->d_srec, (void *)b->d_counts, (void *)b->d_vis,
+                  (void *)b->d_prim, (void *)b->d_fb})
+    if (p) (void)hipFree(p);
+  for (auto &e : b->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (b->ev_copy) (void)hipEventDestroy(b->ev_copy);
+  if (b->h_poses) (void)hipHostFree(b->h_poses);
+  delete b;
+}
+
+rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32_t height, uint32_t max_poses,
+                                rdoom_batch **out_batch) {
+  if (!level || !out_batch) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out_batch = nullptr;
+  if (width == 0 || height == 0 || max_poses == 0 || width % 4 != 0 || width > 16384 || height > 16384)
+    return rdoom::fail(RDOOM_BAD_ARG, "bad frame size %ux%u (width must be a multiple of 4) or max_poses %u", width,
+                       height, max_poses);
+  rdoom_batch *b = new rdoom_batch;
+  b->level = level;
+  b->width = width;
+  b->height = height;
+  b->max_poses = max_poses;
+  b->cap = level->ntri ? level->ntri : 1;
+  const size_t npx = (size_t)width * height * max_poses;
+  hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_rrec, sizeof(RasterRec) * (size_t)b->cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_srec, sizeof(ShadeRec) * (size_t)b->cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, sizeof(uint32_t) * npx);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
+  for (auto &ev : b->ev)
+    if (e == hipSuccess) e = hipEventCreate(&ev);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev_copy);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_poses, sizeof(PoseConst) * max_poses, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    rdoom_batch_destroy(b);
+    return rdoom::fail(e == hipErrorOutOfMemory ? RDOOM_OOM : RDOOM_HIP_ERROR, "batch allocation failed: %s",
+                       hipGetErrorString(e));
+  }
+  *out_batch = b;
+  return RDOOM_OK;
+}
+
+static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const uint8_t *lights, uint32_t lights_stride,
+                                uint32_t n, uint32_t kinds_mask, hipStream_t st, rdoom_timings *tm) {
+  if (!b || !poses || !lights) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  if (n == 0 || n > b->max_poses) return rdoom::fail(RDOOM_BAD_ARG, "n_poses %u outside 1..%u", n, b->max_poses);
+  const rdoom_level *lv = b->level;
+  HIP_TRY(hipEventSynchronize(b->ev_copy));  // previous render's H2D must be done before restaging
+  for (uint32_t p = 0; p < n; p++) {  // V1: PM = P * M, plain multiply/add, left to right
+    PoseConst &pc = b->h_poses[p];
+    const float *P = poses[p].projection, *M = poses[p].modelview;
+    for (int c = 0; c < 4; c++)
+      for (int r = 0; r < 4; r++)
+        pc.pm[c * 4 + r] =
+            ((P[0 * 4 + r] * M[c * 4 + 0] + P[1 * 4 + r] * M[c * 4 + 1]) + P[2 * 4 + r] * M[c * 4 + 2]) +
+            P[3 * 4 + r] * M[c * 4 + 3];
+    pc.time = poses[p].time;
+    pc.vr0 = atan2f(pc.pm[8], pc.pm[10]);  // sky.vert:10-12
+    pc.vr1 = pc.pm[9] / pc.pm[11];
+    pc.pad = 0;
+    std::memcpy(pc.lights, lights + (size_t)p * lights_stride, 256);
+  }
+  b->last_n = n;
+  if (tm) HIP_TRY(hipEventRecord(b->ev[0], st));
+  HIP_TRY(hipMemcpyAsync(b->d_poses, b->h_poses, sizeof(PoseConst) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(b->ev_copy, st));
+  HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
+  const int W = (int)b->width, H = (int)b->height;
+  if (lv->ntri) {
+    dim3 grid((lv->ntri + 255) / 256, n);
+    hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, st, lv->view, b->d_poses, W, H, kinds_mask, b->d_rrec,
+                       b->d_srec, b->d_counts, b->cap);
+  }
+  if (tm) HIP_TRY(hipEventRecord(b->ev[1], st));
+  const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+  const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)(tiles_x * tiles_y);
+  if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
+  hipLaunchKernelGGL(raster_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_rrec, b->d_srec,
+                     b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_vis, b->want_prim ? b->d_prim : nullptr);
+  if (tm) HIP_TRY(hipEventRecord(b->ev[2], st));
+  const uint64_t n_quads = (uint64_t)n * (uint64_t)H * (uint64_t)(W / 4);
+  const uint64_t fblocks = (n_quads + (uint64_t)FRAG_CHUNK * 256 - 1) / ((uint64_t)FRAG_CHUNK * 256);
+  hipLaunchKernelGGL(fragment_kernel, dim3((uint32_t)fblocks), dim3(256), 0, st, lv->view, b->d_srec, b->cap,
+                     b->d_poses, b->d_vis, n_quads, W, H, b->d_fb);
+  HIP_TRY(hipGetLastError());
+  if (tm) {
+    HIP_TRY(hipEventRecord(b->ev[3], st));
+    HIP_TRY(hipEventSynchronize(b->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&tm->setup_ms, b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&tm->raster_ms, b->ev[1], b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&tm->fragment_ms, b->ev[2], b->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&tm->total_ms, b->ev[0], b->ev[3]));
+    tm->pixels = (uint64_t)n * W * H;
+    std::vector<uint32_t> counts(n);
+    HIP_TRY(hipMemcpy(counts.data(), b->d_counts, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    tm->visible_triangles = 0;
+    for (uint32_t c : counts) tm->visible_triangles += c;
+  }
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_batch_render(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream) {
+  return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, nullptr);
+}
+
+rdoom_status rdoom_batch_render_timed(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                      uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
+                                      rdoom_timings *out) {
+  if (!out) return rdoom::fail(RDOOM_BAD_ARG, "out is null");
+  return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, out);
+}
+
+rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **out_device_ptr) {
+  if (!batch || !out_device_ptr) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out_device_ptr = batch->d_fb;
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *b, uint32_t first, uint32_t count, uint8_t *host_out) {
+  if (!b || !host_out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  if ((uint64_t)first + count > b->last_n) return rdoom::fail(RDOOM_BAD_ARG, "frame range outside the last render");
+  const size_t frame = (size_t)b->width * b->height;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_out, b->d_fb + frame * first, frame * count, hipMemcpyDeviceToHost));
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_batch_read_primitive_ids(rdoom_batch *b, uint32_t first, uint32_t count, uint32_t *host_out) {
+  if (!b || !host_out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  if (!b->want_prim || !b->d_prim) {
+    // enable capture lazily; the caller must render again
+    const size_t npx = (size_t)b->width * b->height * b->max_poses;
+    if (!b->d_prim) HIP_TRY(hipMalloc((void **)&b->d_prim, sizeof(uint32_t) * npx));
+    b->want_prim = true;
+    return rdoom::fail(RDOOM_BAD_ARG, "primitive-id capture enabled now; render again, then read");
+  }
+  if ((uint64_t)first + count > b->last_n) return rdoom::fail(RDOOM_BAD_ARG, "frame range outside the last render");
+  const size_t frame = (size_t)b->width * b->height;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_out, b->d_prim + frame * first, frame * count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return RDOOM_OK;
+}
+
+}  // extern "C"

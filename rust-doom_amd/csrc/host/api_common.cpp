@@ -1,0 +1,49 @@
+// C ABI pieces that do not belong to a subsystem: last-error storage and the camera helper.
+#include <cmath>
+#include <cstring>
+
+#include "../common.hpp"
+
+namespace rdoom {
+std::string &last_error_ref() {
+  static thread_local std::string err;
+  return err;
+}
+}  // namespace rdoom
+
+extern "C" {
+
+const char *rdoom_last_error(void) { return rdoom::last_error_ref().c_str(); }
+
+// Camera of the reference (game/src/player.rs:84-89, 325-345; engine/src/projections.rs:93-101;
+// engine/src/renderer.rs:78-87).  The matrices are *inputs* of the renderer, so this helper may use
+// double precision internally; what matters is that every consumer is handed the same 32 floats.
+rdoom_status rdoom_pose_look(const float eye[3], float yaw, float pitch, uint32_t width, uint32_t height, float time,
+                             rdoom_pose *out) {
+  if (!eye || !out || width == 0 || height == 0) return rdoom::fail(RDOOM_BAD_ARG, "bad argument");
+  const double cy = std::cos((double)yaw), sy = std::sin((double)yaw), cp = std::cos((double)pitch),
+               sp = std::sin((double)pitch);
+  // R = Ry(yaw) * Rx(pitch); view = [R^T | -R^T eye]
+  const double R[3][3] = {{cy, sy * sp, sy * cp}, {0.0, cp, -sp}, {-sy, cy * sp, cy * cp}};
+  std::memset(out, 0, sizeof *out);
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) out->modelview[c * 4 + r] = (float)R[c][r];  // (R^T)[r][c] = R[c][r]
+  for (int r = 0; r < 3; r++) {
+    double t = 0;
+    for (int k = 0; k < 3; k++) t -= R[k][r] * (double)eye[k];
+    out->modelview[12 + r] = (float)t;
+  }
+  out->modelview[15] = 1.0f;
+  const float fovy = 65.0f, near_ = 0.01f, far_ = 100.0f;
+  const float aspect = ((float)width / (float)height) * 1.2f;
+  const float f = (float)(1.0 / std::tan((double)fovy * M_PI / 360.0));
+  out->projection[0] = f / aspect;
+  out->projection[5] = f;
+  out->projection[10] = (far_ + near_) / (near_ - far_);
+  out->projection[11] = -1.0f;
+  out->projection[14] = (2.0f * far_ * near_) / (near_ - far_);
+  out->time = time;
+  return RDOOM_OK;
+}
+
+}  // extern "C"
