@@ -21,7 +21,7 @@
 namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr int TILE_W = 32, TILE_H = 32;  // one 256-thread workgroup, 4 pixels (a 4x1 strip) per lane
+constexpr int TILE_W = 64, TILE_H = 64;  // one 256-thread workgroup: 4 waves x 32x32 quadrant, 4x4 pixels per lane
 constexpr int QCAP = 256;
 
 // ---- level-constant triangle record (built once per level on the host) -----------------------
@@ -30,7 +30,7 @@ struct alignas(16) LevelTri {  // 96 bytes
   float uv[6];
   float scroll[3];
   float atlas_u, atlas_v, size_x, size_y, row_height;
-  uint32_t packed;  // num_frames | light << 8 | kind << 16 | masked << 18
+  uint32_t packed;  // num_frames | light << 8 | kind << 16 | masked border << 18 | masked interior << 19
 };
 static_assert(sizeof(LevelTri) == 96, "LevelTri layout");
 
@@ -47,20 +47,31 @@ struct alignas(16) RasterRec {  // 80 bytes
   float zp[3];                  // window-depth plane
   float wp[3];                  // 1/w plane
   uint32_t bb0, bb1;            // x0 | y0 << 16, x1 | y1 << 16 (inclusive)
-  uint32_t flags;               // prim id (24 bits) | tl << 24 | kind << 27 | masked << 29
+  uint32_t flags;               // prim id (24 bits) | tl << 24 | kind << 27 | RASTER_MASKED_*
   uint32_t pad[2];
 };
 static_assert(sizeof(RasterRec) == 80, "RasterRec layout");
+
+constexpr uint32_t RASTER_MASKED_BORDER = 1u << 29;    // a texel bordering the texture rectangle is transparent
+constexpr uint32_t RASTER_MASKED_INTERIOR = 1u << 30;  // the texture rectangle itself has transparent texels
+constexpr uint32_t RASTER_MASKED_ANY = RASTER_MASKED_BORDER | RASTER_MASKED_INTERIOR;
+constexpr uint32_t SHADE_POW2_X = 1u << 2, SHADE_POW2_Y = 1u << 3;
 
 struct alignas(16) ShadeRec {  // 64 bytes
   float wp[3];
   float up[3];
   float vp[3];
   float atlas_u, atlas_v, size_x, size_y, light;
-  uint32_t kind;
-  uint32_t pad;
+  uint32_t flags;  // kind (2 bits) | SHADE_POW2_X | SHADE_POW2_Y
+  uint32_t prim;
 };
 static_assert(sizeof(ShadeRec) == 64, "ShadeRec layout");
+
+struct alignas(16) TriRec {  // 144 bytes = 9 x 16 B: what one (pose, visible triangle) carries
+  RasterRec r;
+  ShadeRec s;
+};
+static_assert(sizeof(TriRec) == 144, "TriRec layout");
 
 struct DeviceLevelView {
   const LevelTri *tris;
@@ -91,7 +102,7 @@ __device__ __forceinline__ float glsl_mod(float x, float y) { return x - y * flo
 // =================================================================================================
 __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
                                                     int width, int height, uint32_t kinds_mask,
-                                                    RasterRec *__restrict__ rrec, ShadeRec *__restrict__ srec,
+                                                    TriRec *__restrict__ recs, uint2 *__restrict__ bboxes,
                                                     uint32_t *__restrict__ counts, uint32_t cap) {
   const uint32_t pose = blockIdx.y;
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
           }
           rr.bb0 = (uint32_t)x0 | ((uint32_t)y0 << 16);
           rr.bb1 = (uint32_t)x1 | ((uint32_t)y1 << 16);
-          const uint32_t masked = (tri.packed >> 18) & 1u;
+          const uint32_t masked = (tri.packed >> 18) & 3u;  // border, interior
           rr.flags = (t & 0xFFFFFFu) | (tl << 24) | (kind << 27) | (masked << 29);
           rr.pad[0] = rr.pad[1] = 0;
           sr.wp[0] = rr.wp[0];
@@ -200,8 +211,10 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
           sr.size_x = tri.size_x;
           sr.size_y = tri.size_y;
           sr.light = (float)pc.lights[(tri.packed >> 8) & 0xFFu] / 255.0f;
-          sr.kind = kind;
-          sr.pad = t;
+          const uint32_t bx = __float_as_uint(tri.size_x), by = __float_as_uint(tri.size_y);
+          sr.flags = kind | (((bx & 0x7FFFFFu) == 0u && tri.size_x > 0.0f) ? SHADE_POW2_X : 0u) |
+                     (((by & 0x7FFFFFu) == 0u && tri.size_y > 0.0f) ? SHADE_POW2_Y : 0u);
+          sr.prim = t;
         }
       }
     }
@@ -217,44 +230,73 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
   base = __shfl(base, leader);
   if (ok) {
     const size_t o = (size_t)pose * cap + base + rank;
-    rrec[o] = rr;
-    srec[o] = sr;
+    recs[o].r = rr;
+    recs[o].s = sr;
+    bboxes[o] = make_uint2(rr.bb0, rr.bb1);
   }
 }
 
-// texel fetch shared by the alpha test (R6) and the fragment stage (F1..F3)
-__device__ __forceinline__ uint32_t fetch_texel(const DeviceLevelView &lv, const ShadeRec &s, float px, float py,
-                                                float &dist) {
-  const float rw = plane3(s.wp, px, py);
+// F1..F3: perspective-correct tile coordinates -> atlas texel coordinates (shared by the alpha test
+// R6 and the fragment stage).  `row_u`/`row_v`/`row_w` are fmaf(B, py, C) of the three planes.
+struct TexelAt {
+  int ix, iy;
+  float dist;
+};
+__device__ __forceinline__ TexelAt texel_coords(const ShadeRec &s, float px, float row_w, float row_u,
+                                                float row_v) {
+  TexelAt t;
+  const float rw = fmaf(s.wp[0], px, row_w);
   const float w = 1.0f / rw;
-  const float tu = plane3(s.up, px, py) * w;
-  const float tv = plane3(s.vp, px, py) * w;
-  dist = w;
-  const float uvx = glsl_mod(tu, s.size_x) + s.atlas_u;
-  const float uvy = glsl_mod(tv, s.size_y) + s.atlas_v;
-  const int ix = (int)floorf(uvx), iy = (int)floorf(uvy);
-  if (s.kind == RDOOM_KIND_FLAT)
+  const float tu = fmaf(s.up[0], px, row_u) * w;
+  const float tv = fmaf(s.vp[0], px, row_v) * w;
+  t.dist = w;
+  // mod(x, y) = x - y * floor(x / y).  For power-of-two y, x / y == x * (1 / y) exactly, and 1 / y is
+  // one integer subtraction on the exponent field: same bits as the division, a tenth of the cost.
+  float qx, qy;
+  if (s.flags & SHADE_POW2_X)
+    qx = tu * __uint_as_float(0x7F000000u - __float_as_uint(s.size_x));
+  else
+    qx = tu / s.size_x;
+  if (s.flags & SHADE_POW2_Y)
+    qy = tv * __uint_as_float(0x7F000000u - __float_as_uint(s.size_y));
+  else
+    qy = tv / s.size_y;
+  const float uvx = (tu - s.size_x * floorf(qx)) + s.atlas_u;
+  const float uvy = (tv - s.size_y * floorf(qy)) + s.atlas_v;
+  t.ix = (int)floorf(uvx);
+  t.iy = (int)floorf(uvy);
+  return t;
+}
+
+__device__ __forceinline__ uint32_t load_texel(const DeviceLevelView &lv, uint32_t kind, int ix, int iy) {
+  if (kind == RDOOM_KIND_FLAT)
     return lv.flat_atlas[(size_t)(iy & (int)(lv.flat_h - 1)) * lv.flat_w + (size_t)(ix & (int)(lv.flat_w - 1))];
   return lv.wall_atlas[(size_t)(iy & (int)(lv.wall_h - 1)) * lv.wall_w + (size_t)(ix & (int)(lv.wall_w - 1))];
 }
 
 // =================================================================================================
-// Kernel 2: tiled rasteriser.  One 256-thread workgroup per (pose, 32x32 tile).  Lanes first act
-// as triangles (bbox-vs-tile test, survivors are staged into an LDS queue), then as pixels: every
-// lane owns a 4x1 strip and keeps its depth / winner in registers while the queue is replayed
-// from LDS (broadcast reads).  Winner = lexicographic min of (d24, primitive id): order-free.
-// blockIdx -> (pose, tile) keeps all tiles of a pose on one XCD (b % 8) so its records stay in
-// that XCD's L2.
+// Kernel 2: tiled rasteriser.  One 256-thread workgroup per (pose, 64x64 tile); each wavefront owns
+// a 32x32 quadrant and each lane a 4x4 pixel block whose depth / winner live in registers.
+//   coarse  lanes act as triangles: bbox-vs-tile test on a packed bbox array, survivors are
+//           compacted IN ORDER (ballot + prefix) and their 144-byte records staged into LDS;
+//   fine    every wave replays the LDS queue (broadcast reads).  Rejection is hierarchical and
+//           exact: fmaf is monotone in each argument, so the extreme of a *computed* edge function
+//           or depth plane over a pixel rectangle sits at a corner -- quadrant vs bbox, then per
+//           lane: three edge corners + nearest-corner depth against the lane's farthest pixel
+//           (early-z).  One __any() skips the 16-pixel body when no lane needs it.
+// Winner = lexicographic min of (d24, primitive id): independent of processing order.
+// blockIdx -> (pose, tile) keeps all tiles of a pose on one XCD (b % 8): its records stay in that
+// XCD's L2.
 // =================================================================================================
-__global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const RasterRec *__restrict__ rrec,
-                                                     const ShadeRec *__restrict__ srec,
+__global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+                                                     const uint2 *__restrict__ bboxes,
                                                      const uint32_t *__restrict__ counts, uint32_t cap,
                                                      uint32_t n_poses, int width, int height, int tiles_x,
                                                      int tiles_y, uint32_t *__restrict__ vis,
                                                      uint32_t *__restrict__ prim_out) {
-  __shared__ RasterRec q[QCAP];
+  __shared__ TriRec q[QCAP];
   __shared__ uint32_t qidx[QCAP];
-  __shared__ uint32_t qn;
+  __shared__ uint32_t wcnt[4];
   const uint32_t b = blockIdx.x;
   const uint32_t T = (uint32_t)(tiles_x * tiles_y);
   const uint32_t g = b >> 3;
@@ -262,87 +304,145 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const R
   const uint32_t tile = g % T;
   if (pose >= n_poses) return;
   const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE_W, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE_H;
-  const int tid = threadIdx.x;
-  const int sx = tx0 + (tid & 7) * 4, sy = ty0 + (tid >> 3);
-  const float py = (float)sy + 0.5f;
-  uint32_t best_d[4], best_p[4], best_r[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int qx0 = tx0 + (wave & 1) * 32, qy0 = ty0 + (wave >> 1) * 32;  // this wave's quadrant
+  const int bx = qx0 + (lane & 7) * 4, by = qy0 + (lane >> 3) * 4;      // this lane's 4x4 block
+  const float pxlo = (float)bx + 0.5f, pxhi = (float)bx + 3.5f, pylo = (float)by + 0.5f, pyhi = (float)by + 3.5f;
+  uint32_t best_d[16], best_r[16];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 16; k++) {
     best_d[k] = NONE;
-    best_p[k] = NONE;
     best_r[k] = NONE;
   }
-  if (tid == 0) qn = 0;
-  __syncthreads();
+  uint32_t lane_far = NONE;  // max of best_d: the farthest depth this lane still holds
   const uint32_t count = counts[pose];
-  const RasterRec *prr = rrec + (size_t)pose * cap;
-  const ShadeRec *psr = srec + (size_t)pose * cap;
+  const TriRec *prec = recs + (size_t)pose * cap;
+  const uint2 *pbb = bboxes + (size_t)pose * cap;
   for (uint32_t base = 0; base < count; base += 256u) {
+    // ---- coarse: one triangle per lane, ordered compaction ---------------------------------------
     const uint32_t i = base + (uint32_t)tid;
+    bool hit = false;
     if (i < count) {
-      const uint32_t bb0 = prr[i].bb0, bb1 = prr[i].bb1;
-      const int x0 = (int)(bb0 & 0xFFFFu), y0 = (int)(bb0 >> 16), x1 = (int)(bb1 & 0xFFFFu), y1 = (int)(bb1 >> 16);
-      if (x0 <= tx0 + TILE_W - 1 && x1 >= tx0 && y0 <= ty0 + TILE_H - 1 && y1 >= ty0) {
-        const uint32_t slot = atomicAdd(&qn, 1u);
-        q[slot] = prr[i];
-        qidx[slot] = i;
-      }
+      const uint2 bb = pbb[i];
+      const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
+      hit = x0 <= tx0 + TILE_W - 1 && x1 >= tx0 && y0 <= ty0 + TILE_H - 1 && y1 >= ty0;
+    }
+    const unsigned long long hm = __ballot(hit);
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(hm);
+    __syncthreads();
+    uint32_t off = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull)), n = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint32_t c = wcnt[w];
+      if (w < wave) off += c;
+      n += c;
+    }
+    if (hit) qidx[off] = i;
+    __syncthreads();
+    // cooperative staging: 9 x 16-byte chunks per record
+    for (uint32_t c = (uint32_t)tid; c < n * 9u; c += 256u) {
+      const uint32_t e = c / 9u, k = c - e * 9u;
+      reinterpret_cast<uint4 *>(&q[e])[k] = reinterpret_cast<const uint4 *>(&prec[qidx[e]])[k];
     }
     __syncthreads();
-    const uint32_t n = qn;
+    // ---- fine: each wave walks the queue for its own quadrant ------------------------------------
     for (uint32_t j = 0; j < n; j++) {
-      const RasterRec &r = q[j];
+      const RasterRec &r = q[j].r;
       const int x0 = (int)(r.bb0 & 0xFFFFu), y0 = (int)(r.bb0 >> 16), x1 = (int)(r.bb1 & 0xFFFFu),
                 y1 = (int)(r.bb1 >> 16);
-      if (sy < y0 || sy > y1 || sx + 3 < x0 || sx > x1) continue;
+      if (x0 > qx0 + 31 || x1 < qx0 || y0 > qy0 + 31 || y1 < qy0) continue;  // wave-uniform
       const uint32_t flags = r.flags;
-      const uint32_t prim = flags & 0xFFFFFFu;
-      const uint32_t ridx = qidx[j];
       const float e0a = r.e[0], e0b = r.e[1], e0c = r.e[2], e1a = r.e[3], e1b = r.e[4], e1c = r.e[5], e2a = r.e[6],
                   e2b = r.e[7], e2c = r.e[8];
-      const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
-      const float tz = fmaf(r.zp[1], py, r.zp[2]), tw = fmaf(r.wp[1], py, r.wp[2]);
+      const float za = r.zp[0], zb = r.zp[1], zc = r.zp[2];
+      // lane-level exact rejection: largest edge values and nearest depth over my 4x4 block
+      const float m0 = fmaf(e0a, e0a > 0.0f ? pxhi : pxlo, fmaf(e0b, e0b > 0.0f ? pyhi : pylo, e0c));
+      const float m1 = fmaf(e1a, e1a > 0.0f ? pxhi : pxlo, fmaf(e1b, e1b > 0.0f ? pyhi : pylo, e1c));
+      const float m2 = fmaf(e2a, e2a > 0.0f ? pxhi : pxlo, fmaf(e2b, e2b > 0.0f ? pyhi : pylo, e2c));
+      const float zn = fmaf(za, za > 0.0f ? pxlo : pxhi, fmaf(zb, zb > 0.0f ? pylo : pyhi, zc));
+      const float zf = fmaf(za, za > 0.0f ? pxhi : pxlo, fmaf(zb, zb > 0.0f ? pyhi : pylo, zc));
+      const uint32_t dn = (uint32_t)fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f);
+      const bool need = bx <= x1 && bx + 3 >= x0 && by <= y1 && by + 3 >= y0 && m0 >= 0.0f && m1 >= 0.0f &&
+                        m2 >= 0.0f && zn <= 1.0f && zf >= 0.0f && dn <= lane_far;
+      if (!__any(need)) continue;
+      if (!need) continue;
+      const uint32_t prim = flags & 0xFFFFFFu;
+      const uint32_t ridx = qidx[j];
+      const float wa = r.wp[0], wb = r.wp[1], wc = r.wp[2];
+      bool updated = false;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int ix = sx + k;
-        const float px = (float)ix + 0.5f;
-        const float e0 = fmaf(e0a, px, t0), e1 = fmaf(e1a, px, t1), e2 = fmaf(e2a, px, t2);
-        const bool in0 = (e0 > 0.0f) || (e0 == 0.0f && (flags & (1u << 24)) != 0u);
-        const bool in1 = (e1 > 0.0f) || (e1 == 0.0f && (flags & (1u << 25)) != 0u);
-        const bool in2 = (e2 > 0.0f) || (e2 == 0.0f && (flags & (1u << 26)) != 0u);
-        const float zw = fmaf(r.zp[0], px, tz);
-        const float rw = fmaf(r.wp[0], px, tw);
-        const uint32_t d24 = (uint32_t)fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f);
-        bool pass = ix >= x0 && ix <= x1 && in0 && in1 && in2 && zw >= 0.0f && zw <= 1.0f && rw > 0.0f &&
-                    (d24 < best_d[k] || (d24 == best_d[k] && prim < best_p[k]));
-        if (pass && (flags & (1u << 29)) != 0u) {  // masked wall texture: alpha test before the depth write
-          float dist;
-          const uint32_t texel = fetch_texel(lv, psr[ridx], px, py, dist);
-          pass = (texel & 0x8000u) == 0u;
+      for (int ry = 0; ry < 4; ry++) {
+        const int iy = by + ry;
+        const float py = (float)iy + 0.5f;
+        const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
+        const float tz = fmaf(zb, py, zc), tw = fmaf(wb, py, wc);
+        const bool rowin = iy >= y0 && iy <= y1;
+#pragma unroll
+        for (int rx = 0; rx < 4; rx++) {
+          const int k = ry * 4 + rx;
+          const int ix = bx + rx;
+          const float px = (float)ix + 0.5f;
+          const float e0 = fmaf(e0a, px, t0), e1 = fmaf(e1a, px, t1), e2 = fmaf(e2a, px, t2);
+          const bool in0 = (e0 > 0.0f) || (e0 == 0.0f && (flags & (1u << 24)) != 0u);
+          const bool in1 = (e1 > 0.0f) || (e1 == 0.0f && (flags & (1u << 25)) != 0u);
+          const bool in2 = (e2 > 0.0f) || (e2 == 0.0f && (flags & (1u << 26)) != 0u);
+          const float zw = fmaf(za, px, tz);
+          const float rw = fmaf(wa, px, tw);
+          const uint32_t d24 = (uint32_t)fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f);
+          bool pass = rowin && ix >= x0 && ix <= x1 && in0 && in1 && in2 && zw >= 0.0f && zw <= 1.0f && rw > 0.0f &&
+                      d24 <= best_d[k];
+          if (pass && d24 == best_d[k])  // depth tie (rare): the earlier primitive keeps the pixel
+            pass = best_r[k] == NONE || prim < (prec[best_r[k]].r.flags & 0xFFFFFFu);
+          if (pass && (flags & RASTER_MASKED_ANY) != 0u) {  // R6: alpha test before the depth write
+            const ShadeRec &s = q[j].s;
+            const TexelAt t = texel_coords(s, px, tw, fmaf(s.up[1], py, s.up[2]), fmaf(s.vp[1], py, s.vp[2]));
+            // texture rectangle fully opaque: only a coordinate that the float mod pushed just outside
+            // the rectangle can hit a transparent neighbour texel -- fetch only then
+            const bool must_fetch = (flags & RASTER_MASKED_INTERIOR) != 0u || t.ix < (int)s.atlas_u ||
+                                    t.ix >= (int)(s.atlas_u + s.size_x) || t.iy < (int)s.atlas_v ||
+                                    t.iy >= (int)(s.atlas_v + s.size_y);
+            if (must_fetch) pass = (load_texel(lv, RDOOM_KIND_WALL, t.ix, t.iy) & 0x8000u) == 0u;
+          }
+          if (pass) {
+            best_d[k] = d24;
+            best_r[k] = ridx;
+            updated = true;
+          }
         }
-        if (pass) {
-          best_d[k] = d24;
-          best_p[k] = prim;
-          best_r[k] = ridx;
-        }
+      }
+      if (updated) {
+        uint32_t m = best_d[0];
+#pragma unroll
+        for (int k = 1; k < 16; k++) m = max(m, best_d[k]);
+        lane_far = m;
       }
     }
     __syncthreads();
-    if (tid == 0) qn = 0;
-    __syncthreads();
   }
-  if (sy < height && sx < width) {
-    const size_t o = ((size_t)pose * (size_t)height + (size_t)sy) * (size_t)width + (size_t)sx;
-    *reinterpret_cast<uint4 *>(vis + o) = make_uint4(best_r[0], best_r[1], best_r[2], best_r[3]);
-    if (prim_out) *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(best_p[0], best_p[1], best_p[2], best_p[3]);
+#pragma unroll
+  for (int ry = 0; ry < 4; ry++) {
+    const int iy = by + ry;
+    if (iy < height && bx < width) {
+      const size_t o = ((size_t)pose * (size_t)height + (size_t)iy) * (size_t)width + (size_t)bx;
+      *reinterpret_cast<uint4 *>(vis + o) =
+          make_uint4(best_r[ry * 4], best_r[ry * 4 + 1], best_r[ry * 4 + 2], best_r[ry * 4 + 3]);
+      if (prim_out) {
+        uint32_t p[4];
+#pragma unroll
+        for (int rx = 0; rx < 4; rx++)
+          p[rx] = best_r[ry * 4 + rx] == NONE ? NONE : (prec[best_r[ry * 4 + rx]].r.flags & 0xFFFFFFu);
+        *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p[0], p[1], p[2], p[3]);
+      }
+    }
   }
 }
 
 // =================================================================================================
 // Kernel 3: fragment kernel (F1..F6): visibility record -> atlas texel -> COLORMAP row -> 8-bit
 // palette index.  One lane per 4 horizontally adjacent pixels: one 16-byte visibility load, one
-// 4-byte packed store.  COLORMAP (8 KiB) is staged in LDS once per workgroup; a workgroup walks
-// CHUNK consecutive 1024-pixel slabs so that staging is amortised.
+// 4-byte packed store.  When the four pixels see the same triangle (the common case) its 64-byte
+// shade record is loaded once and the row terms of the three planes are shared.  COLORMAP (8 KiB)
+// is staged in LDS once per workgroup; a workgroup walks FRAG_CHUNK consecutive 1024-pixel slabs.
 // =================================================================================================
 constexpr int FRAG_CHUNK = 16;
 
@@ -370,7 +470,21 @@ __device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const u
   return cmap[texel & 0xFFu];
 }
 
-__global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const ShadeRec *__restrict__ srec,
+__device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const uint8_t *cmap, const ShadeRec &s,
+                                                float px, float py, float row_w, float row_u, float row_v,
+                                                int width, int height, const PoseConst &pc) {
+  const uint32_t kind = s.flags & 3u;
+  if (kind == RDOOM_KIND_SKY) return shade_sky(lv, cmap, px, py, width, height, pc.vr0, pc.vr1);
+  const TexelAt t = texel_coords(s, px, row_w, row_u, row_v);
+  const uint32_t texel = load_texel(lv, kind, t.ix, t.iy);
+  const float dist_term = fminf(1.0f, 1.0f - 0.9f / (t.dist + 0.9f));
+  const float light = s.light * 2.0f - dist_term;
+  const float tt = (1.0f - light) * 32.0f;
+  const int rowc = tt < 0.0f ? 0 : (tt >= 32.0f ? 31 : (int)floorf(tt));
+  return cmap[rowc * 256 + (int)(texel & 0xFFu)];
+}
+
+__global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
                                                        const uint32_t *__restrict__ vis, uint64_t n_quads,
                                                        int width, int height, uint8_t *__restrict__ fb) {
@@ -391,29 +505,30 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
     const uint32_t rem = (uint32_t)(qi - (uint64_t)pose * quads_per_pose);
     const uint32_t row = rem / quads_per_row, qx = rem - row * quads_per_row;
     const uint4 ids = reinterpret_cast<const uint4 *>(vis)[qi];
-    const uint32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
     const float py = (float)row + 0.5f;
-    const ShadeRec *psr = srec + (size_t)pose * cap;
+    const float px0 = (float)(qx * 4u) + 0.5f;
+    const TriRec *prec = recs + (size_t)pose * cap;
     uint32_t out = 0;
+    if (ids.x == ids.y && ids.x == ids.z && ids.x == ids.w) {
+      if (ids.x != NONE) {
+        const ShadeRec s = prec[ids.x].s;
+        const float row_w = fmaf(s.wp[1], py, s.wp[2]), row_u = fmaf(s.up[1], py, s.up[2]),
+                    row_v = fmaf(s.vp[1], py, s.vp[2]);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      uint32_t c = 0;
-      if (id[k] != NONE) {
-        const float px = (float)(qx * 4u + (uint32_t)k) + 0.5f;
-        const ShadeRec s = psr[id[k]];
-        if (s.kind == RDOOM_KIND_SKY) {
-          c = shade_sky(lv, cmap, px, py, width, height, poses[pose].vr0, poses[pose].vr1);
-        } else {
-          float dist;
-          const uint32_t texel = fetch_texel(lv, s, px, py, dist);
-          const float dist_term = fminf(1.0f, 1.0f - 0.9f / (dist + 0.9f));
-          const float light = s.light * 2.0f - dist_term;
-          const float t = (1.0f - light) * 32.0f;
-          const int rowc = t < 0.0f ? 0 : (t >= 32.0f ? 31 : (int)floorf(t));
-          c = cmap[rowc * 256 + (int)(texel & 0xFFu)];
-        }
+        for (int k = 0; k < 4; k++)
+          out |= shade_pixel(lv, cmap, s, px0 + (float)k, py, row_w, row_u, row_v, width, height, poses[pose])
+                 << (8 * k);
       }
-      out |= c << (8 * k);
+    } else {
+      const uint32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (id[k] == NONE) continue;
+        const ShadeRec s = prec[id[k]].s;
+        out |= shade_pixel(lv, cmap, s, px0 + (float)k, py, fmaf(s.wp[1], py, s.wp[2]), fmaf(s.up[1], py, s.up[2]),
+                           fmaf(s.vp[1], py, s.vp[2]), width, height, poses[pose])
+               << (8 * k);
+      }
     }
     reinterpret_cast<uint32_t *>(fb)[qi] = out;
   }
@@ -445,8 +560,8 @@ struct rdoom_batch {
   const rdoom_level *level = nullptr;
   uint32_t width = 0, height = 0, max_poses = 0, cap = 0, last_n = 0;
   PoseConst *d_poses = nullptr;
-  RasterRec *d_rrec = nullptr;
-  ShadeRec *d_srec = nullptr;
+  TriRec *d_recs = nullptr;   // max_poses x cap records (setup -> raster, fragment)
+  uint2 *d_bbox = nullptr;    // packed pixel bboxes of the same records (coarse test)
   uint32_t *d_counts = nullptr, *d_vis = nullptr, *d_prim = nullptr;
   uint8_t *d_fb = nullptr;
   PoseConst *h_poses = nullptr;  // pinned staging for the per-pose constants
@@ -487,31 +602,33 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
     return rdoom::fail(RDOOM_BAD_ARG, "wall atlas %ux%u is not a power of two", d->wall_w, d->wall_h);
   // flatten the draws into one primitive list in draw order (primitive id == position)
   std::vector<LevelTri> tris;
-  std::map<std::tuple<float, float, float, float, uint32_t, float>, bool> masked_cache;
-  auto region_masked = [&](const rdoom_static_vertex &v) -> bool {
+  // Alpha-test classification of a wall texture (all its animation frames): bit 0 = a texel in the
+  // one-texel ring AROUND the rectangle is transparent (the float mod of F2 can land there), bit 1 =
+  // the rectangle itself contains transparent texels (a genuinely masked texture).
+  std::map<std::tuple<float, float, float, float, uint32_t, float>, uint32_t> masked_cache;
+  auto region_masked = [&](const rdoom_static_vertex &v) -> uint32_t {
     auto key = std::make_tuple(v.a_atlas_uv[0], v.a_atlas_uv[1], v.a_tile_size[0], v.a_tile_size[1],
                                (uint32_t)v.a_num_frames, v.a_row_height);
     auto it = masked_cache.find(key);
     if (it != masked_cache.end()) return it->second;
-    bool m = false;
+    uint32_t m = 0;
     const double W = d->wall_w, au = v.a_atlas_uv[0], av = v.a_atlas_uv[1], sx = v.a_tile_size[0],
                  sy = v.a_tile_size[1];
     const uint32_t nf = v.a_num_frames == 0 ? 1u : v.a_num_frames;
-    for (uint32_t f = 0; f < nf && !m; f++) {
+    for (uint32_t f = 0; f < nf; f++) {
       double u0 = au + f * sx;
       double rows = std::ceil((u0 + sx) / W) - 1.0;
       if (nf == 1) rows = 0;
-      double md = sx > 0 ? (W - au) - sx * std::floor((W - au) / sx) : 0;
+      const double md = sx > 0 ? (W - au) - sx * std::floor((W - au) / sx) : 0;
       u0 += md * rows;
-      double v0 = av + rows * v.a_row_height;
-      // one texel of margin on every side: the float mod may land one texel outside the rectangle
-      for (long y = (long)std::floor(v0) - 1; y <= (long)std::ceil(v0 + sy) && !m; y++)
-        for (long x = (long)std::floor(u0) - 1; x <= (long)std::ceil(u0 + sx); x++) {
+      const double v0 = av + rows * v.a_row_height;
+      const long xlo = (long)std::floor(u0), xhi = (long)std::ceil(u0 + sx), ylo = (long)std::floor(v0),
+                 yhi = (long)std::ceil(v0 + sy);  // interior = [xlo, xhi) x [ylo, yhi)
+      for (long y = ylo - 1; y <= yhi; y++)
+        for (long x = xlo - 1; x <= xhi; x++) {
           const uint32_t xx = (uint32_t)x & (d->wall_w - 1), yy = (uint32_t)y & (d->wall_h - 1);
-          if (d->wall_atlas[(size_t)yy * d->wall_w + xx] & 0x8000u) {
-            m = true;
-            break;
-          }
+          if (d->wall_atlas[(size_t)yy * d->wall_w + xx] & 0x8000u)
+            m |= (x >= xlo && x < xhi && y >= ylo && y < yhi) ? 2u : 1u;
         }
     }
     masked_cache[key] = m;
@@ -543,7 +660,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
         lt.size_x = pv.a_tile_size[0];
         lt.size_y = pv.a_tile_size[1];
         lt.row_height = pv.a_row_height;
-        bool masked = false;
+        uint32_t masked = 0;
         if (dr.kind == RDOOM_KIND_WALL) {
           if (!d->wall_atlas) return rdoom::fail(RDOOM_BAD_ARG, "wall draw without a wall atlas");
           masked = region_masked(pv);
@@ -551,7 +668,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
           return rdoom::fail(RDOOM_BAD_ARG, "flat draw without a flat atlas");
         }
         lt.packed = (uint32_t)pv.a_num_frames | ((uint32_t)pv.a_light << 8) | (dr.kind << 16) |
-                    ((masked ? 1u : 0u) << 18);
+                    (masked << 18);
       } else if (dr.kind == RDOOM_KIND_SKY) {
         if ((uint64_t)dr.first_index + dr.index_count > d->n_sky_indices)
           return rdoom::fail(RDOOM_BAD_ARG, "draw %u: sky index range out of bounds", di);
@@ -608,7 +725,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
 
 void rdoom_batch_destroy(rdoom_batch *b) {
   if (!b) return;
-  for (void *p : {(void *)b->d_poses, (void *)b->d_rrec, (void *)b->d_srec, (void *)b->d_counts, (void *)b->d_vis,
+  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_bbox, (void *)b->d_counts, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb})
     if (p) (void)hipFree(p);
   for (auto &e : b->ev)
@@ -633,8 +750,8 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   b->cap = level->ntri ? level->ntri : 1;
   const size_t npx = (size_t)width * height * max_poses;
   hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_rrec, sizeof(RasterRec) * (size_t)b->cap * max_poses);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_srec, sizeof(ShadeRec) * (size_t)b->cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_bbox, sizeof(uint2) * (size_t)b->cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, sizeof(uint32_t) * npx);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
@@ -679,19 +796,19 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   const int W = (int)b->width, H = (int)b->height;
   if (lv->ntri) {
     dim3 grid((lv->ntri + 255) / 256, n);
-    hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, st, lv->view, b->d_poses, W, H, kinds_mask, b->d_rrec,
-                       b->d_srec, b->d_counts, b->cap);
+    hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, st, lv->view, b->d_poses, W, H, kinds_mask, b->d_recs,
+                       b->d_bbox, b->d_counts, b->cap);
   }
   if (tm) HIP_TRY(hipEventRecord(b->ev[1], st));
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)(tiles_x * tiles_y);
   if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
-  hipLaunchKernelGGL(raster_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_rrec, b->d_srec,
+  hipLaunchKernelGGL(raster_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs, b->d_bbox,
                      b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_vis, b->want_prim ? b->d_prim : nullptr);
   if (tm) HIP_TRY(hipEventRecord(b->ev[2], st));
   const uint64_t n_quads = (uint64_t)n * (uint64_t)H * (uint64_t)(W / 4);
   const uint64_t fblocks = (n_quads + (uint64_t)FRAG_CHUNK * 256 - 1) / ((uint64_t)FRAG_CHUNK * 256);
-  hipLaunchKernelGGL(fragment_kernel, dim3((uint32_t)fblocks), dim3(256), 0, st, lv->view, b->d_srec, b->cap,
+  hipLaunchKernelGGL(fragment_kernel, dim3((uint32_t)fblocks), dim3(256), 0, st, lv->view, b->d_recs, b->cap,
                      b->d_poses, b->d_vis, n_quads, W, H, b->d_fb);
   HIP_TRY(hipGetLastError());
   if (tm) {
