@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <tuple>
@@ -97,19 +99,21 @@ __device__ __forceinline__ float dop(float a, float b, float c, float d) {
 __device__ __forceinline__ float glsl_mod(float x, float y) { return x - y * floorf(x / y); }
 
 // =================================================================================================
-// Kernel 1: vertex stage + triangle setup (V2..V5, S1..S6), one thread per (pose, triangle).
-// Visible triangles are appended per pose with one wave-aggregated atomic per wavefront.
+// Kernel 1: vertex stage + triangle setup (V2..V5, S1..S6) and front-to-back ordering.
+// One 256-thread workgroup per pose walks the level's triangle list in chunks; visible triangles are
+// compacted in order (ballot + prefix) into the pose's record array, then a counting sort over a
+// log-depth bucket (exponent + top mantissa bits of the nearest vertex's w) produces the `sorted`
+// list the rasteriser consumes: near geometry first, so its exact early-z test rejects most occluded
+// triangles.  The order only affects speed: the winner is the lexicographic min of (d24, primitive).
 // =================================================================================================
-__global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
-                                                    int width, int height, uint32_t kinds_mask,
-                                                    TriRec *__restrict__ recs, uint2 *__restrict__ bboxes,
-                                                    uint32_t *__restrict__ counts, uint32_t cap) {
-  const uint32_t pose = blockIdx.y;
-  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-  const PoseConst &pc = poses[pose];
+constexpr uint32_t SORT_BUCKETS = 2048;
+constexpr uint32_t SORT_KEY_CAP = 24576;  // triangles per pose whose keys fit the LDS key array
+
+__device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const PoseConst &pc, uint32_t t, int width,
+                                               int height, uint32_t kinds_mask, RasterRec &rr, ShadeRec &sr,
+                                               float &wkey) {
+  wkey = 0.0f;
   bool ok = t < lv.ntri;
-  RasterRec rr;
-  ShadeRec sr;
   if (ok) {
     const LevelTri tri = lv.tris[t];
     const uint32_t kind = (tri.packed >> 16) & 3u;
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
           rr.zp[2] = rr.zp[2] + 0.5f;
           int x0 = 0, y0 = 0, x1 = width - 1, y1 = height - 1;
           const float wmin = fminf(w[0], fminf(w[1], w[2]));
+          wkey = wmin;
           if (wmin >= 1e-5f) {
             float sx[3], sy[3];
 #pragma unroll
@@ -219,20 +224,87 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
       }
     }
   }
-  // wave-aggregated append: one atomic per wavefront (64 lanes)
-  const unsigned long long mask = __ballot(ok);
-  if (mask == 0ull) return;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if ((int)lane == leader) base = atomicAdd(&counts[pose], (uint32_t)__popcll(mask));
-  base = __shfl(base, leader);
-  if (ok) {
-    const size_t o = (size_t)pose * cap + base + rank;
-    recs[o].r = rr;
-    recs[o].s = sr;
-    bboxes[o] = make_uint2(rr.bb0, rr.bb1);
+  return ok;
+}
+
+__device__ __forceinline__ uint32_t depth_bucket(float wmin) {
+  // monotone in wmin: 16 binades [2^-8, 2^8) x 128 steps; anything nearer (or behind the eye) -> 0
+  if (!(wmin > 0.00390625f)) return 0u;
+  const uint32_t b = (__float_as_uint(wmin) >> 16) - (0x3B80u);  // 0x3B800000 = 2^-8
+  return min(b, SORT_BUCKETS - 1u);
+}
+
+__global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
+                                                    int width, int height, uint32_t kinds_mask,
+                                                    TriRec *__restrict__ recs, uint4 *__restrict__ sorted,
+                                                    uint32_t *__restrict__ counts, uint32_t cap) {
+  __shared__ uint32_t hist[SORT_BUCKETS];
+  __shared__ uint16_t keys[SORT_KEY_CAP];
+  __shared__ uint32_t wcnt[4];
+  __shared__ uint32_t scan_tmp[256];
+  const uint32_t pose = blockIdx.x;
+  const PoseConst &pc = poses[pose];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  TriRec *prec = recs + (size_t)pose * cap;
+  uint4 *psorted = sorted + (size_t)pose * cap;
+  for (uint32_t i = tid; i < SORT_BUCKETS; i += 256) hist[i] = 0;
+  __syncthreads();
+  uint32_t n = 0;  // visible so far (uniform)
+  for (uint32_t base = 0; base < lv.ntri; base += 256u) {
+    const uint32_t t = base + (uint32_t)tid;
+    RasterRec rr;
+    ShadeRec sr;
+    float wkey;
+    const bool ok = t < lv.ntri && setup_triangle(lv, pc, t, width, height, kinds_mask, rr, sr, wkey);
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint32_t c = wcnt[w];
+      if (w < wave) off += c;
+      total += c;
+    }
+    if (ok) {
+      prec[off].r = rr;
+      prec[off].s = sr;
+      const uint32_t bucket = depth_bucket(wkey);
+      if (off < SORT_KEY_CAP) {
+        keys[off] = (uint16_t)bucket;
+        atomicAdd(&hist[bucket], 1u);
+      }
+      psorted[off] = make_uint4(rr.bb0, rr.bb1, off, bucket);  // identity order; overwritten by the sort below
+    }
+    n += total;
+    __syncthreads();
+  }
+  if (tid == 0) counts[pose] = n;
+  if (n > SORT_KEY_CAP) return;  // too many for the LDS key array: leave primitive order (still correct)
+  // exclusive scan of the histogram: 8 buckets per thread + a 256-wide block scan
+  uint32_t local[8], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    local[k] = sum;
+    sum += hist[tid * 8 + k];
+  }
+  scan_tmp[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
+    __syncthreads();
+    scan_tmp[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t before = scan_tmp[tid] - sum;
+#pragma unroll
+  for (int k = 0; k < 8; k++) hist[tid * 8 + k] = before + local[k];
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += 256) {
+    const uint32_t bucket = keys[i];
+    const uint32_t pos = atomicAdd(&hist[bucket], 1u);
+    const RasterRec &r = prec[i].r;  // written above by this workgroup (same CU: L1/L2 coherent after the barrier)
+    psorted[pos] = make_uint4(r.bb0, r.bb1, i, bucket);
   }
 }
 
@@ -288,12 +360,18 @@ __device__ __forceinline__ uint32_t load_texel(const DeviceLevelView &lv, uint32
 // blockIdx -> (pose, tile) keeps all tiles of a pose on one XCD (b % 8): its records stay in that
 // XCD's L2.
 // =================================================================================================
+template <bool STATS>
 __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
-                                                     const uint2 *__restrict__ bboxes,
+                                                     const uint4 *__restrict__ sorted,
                                                      const uint32_t *__restrict__ counts, uint32_t cap,
                                                      uint32_t n_poses, int width, int height, int tiles_x,
                                                      int tiles_y, uint32_t *__restrict__ vis,
-                                                     uint32_t *__restrict__ prim_out) {
+                                                     uint32_t *__restrict__ prim_out,
+                                                     unsigned long long *__restrict__ stats) {
+  // STATS (debug builds of the launch only): [0] queue entries seen by waves, [1] past the quadrant bbox,
+  // [2] past the lane-level rejection (__any(need)), [3] lanes needing, [4] fast bodies, [5] lanes in fast
+  // bodies, [6] general bodies, [7] lanes in general bodies, [8] coarse tests, [9] coarse hits
+  unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __shared__ TriRec q[QCAP];
   __shared__ uint32_t qidx[QCAP];
   __shared__ uint32_t wcnt[4];
@@ -317,17 +395,43 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const T
   uint32_t lane_far = NONE;  // max of best_d: the farthest depth this lane still holds
   const uint32_t count = counts[pose];
   const TriRec *prec = recs + (size_t)pose * cap;
-  const uint2 *pbb = bboxes + (size_t)pose * cap;
+  const uint4 *psorted = sorted + (size_t)pose * cap;
   for (uint32_t base = 0; base < count; base += 256u) {
-    // ---- coarse: one triangle per lane, ordered compaction ---------------------------------------
+    // ---- coarse: one triangle per lane ------------------------------------------------------------
+    // (a) packed bbox vs tile; (b) for the survivors an EXACT per-quadrant test from the record's edge and
+    // depth planes (corner evaluation, see above) -- triangles that cross the eye plane carry a
+    // full-screen bbox, so (b) is what keeps the queues short; (c) ordered compaction + staging.
     const uint32_t i = base + (uint32_t)tid;
-    bool hit = false;
+    uint32_t qm = 0, rec_index = 0;
     if (i < count) {
-      const uint2 bb = pbb[i];
+      const uint4 bb = psorted[i];  // (bb0, bb1, record index, depth bucket), near to far
+      rec_index = bb.z;
       const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
-      hit = x0 <= tx0 + TILE_W - 1 && x1 >= tx0 && y0 <= ty0 + TILE_H - 1 && y1 >= ty0;
+      if (x0 <= tx0 + TILE_W - 1 && x1 >= tx0 && y0 <= ty0 + TILE_H - 1 && y1 >= ty0) {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[rec_index]);
+        const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2];  // e[0..8], zp[0..2]
+        const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
+                    e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
+                    e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x),
+                    za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+          const int rx0 = tx0 + (qd & 1) * 32, ry0 = ty0 + (qd >> 1) * 32;
+          const float xl = (float)rx0 + 0.5f, xh = (float)rx0 + 31.5f, yl = (float)ry0 + 0.5f, yh = (float)ry0 + 31.5f;
+          const float m0 = fmaf(e0a, e0a > 0.0f ? xh : xl, fmaf(e0b, e0b > 0.0f ? yh : yl, e0c));
+          const float m1 = fmaf(e1a, e1a > 0.0f ? xh : xl, fmaf(e1b, e1b > 0.0f ? yh : yl, e1c));
+          const float m2 = fmaf(e2a, e2a > 0.0f ? xh : xl, fmaf(e2b, e2b > 0.0f ? yh : yl, e2c));
+          const float zn = fmaf(za, za > 0.0f ? xl : xh, fmaf(zb, zb > 0.0f ? yl : yh, zc));
+          const float zf = fmaf(za, za > 0.0f ? xh : xl, fmaf(zb, zb > 0.0f ? yh : yl, zc));
+          const bool ok = (x0 <= rx0 + 31) & (x1 >= rx0) & (y0 <= ry0 + 31) & (y1 >= ry0) & (m0 >= 0.0f) &
+                          (m1 >= 0.0f) & (m2 >= 0.0f) & (zn <= 1.0f) & (zf >= 0.0f);
+          qm |= ok ? (1u << qd) : 0u;
+        }
+      }
     }
+    const bool hit = qm != 0u;
     const unsigned long long hm = __ballot(hit);
+    if (STATS) st[8] += (unsigned long long)__popcll(__ballot(i < count)), st[9] += (unsigned long long)__popcll(hm);
     if (lane == 0) wcnt[wave] = (uint32_t)__popcll(hm);
     __syncthreads();
     uint32_t off = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull)), n = 0;
@@ -337,20 +441,24 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const T
       if (w < wave) off += c;
       n += c;
     }
-    if (hit) qidx[off] = i;
+    if (hit) qidx[off] = rec_index | (qm << 28);
     __syncthreads();
     // cooperative staging: 9 x 16-byte chunks per record
     for (uint32_t c = (uint32_t)tid; c < n * 9u; c += 256u) {
       const uint32_t e = c / 9u, k = c - e * 9u;
-      reinterpret_cast<uint4 *>(&q[e])[k] = reinterpret_cast<const uint4 *>(&prec[qidx[e]])[k];
+      reinterpret_cast<uint4 *>(&q[e])[k] = reinterpret_cast<const uint4 *>(&prec[qidx[e] & 0x0FFFFFFFu])[k];
     }
     __syncthreads();
     // ---- fine: each wave walks the queue for its own quadrant ------------------------------------
     for (uint32_t j = 0; j < n; j++) {
+      const uint32_t qe = qidx[j];
+      if (!((qe >> (28 + wave)) & 1u)) continue;  // this triangle cannot touch my quadrant (exact)
       const RasterRec &r = q[j].r;
       const int x0 = (int)(r.bb0 & 0xFFFFu), y0 = (int)(r.bb0 >> 16), x1 = (int)(r.bb1 & 0xFFFFu),
                 y1 = (int)(r.bb1 >> 16);
+      if (STATS) st[0]++;
       if (x0 > qx0 + 31 || x1 < qx0 || y0 > qy0 + 31 || y1 < qy0) continue;  // wave-uniform
+      if (STATS) st[1]++;
       const uint32_t flags = r.flags;
       const float e0a = r.e[0], e0b = r.e[1], e0c = r.e[2], e1a = r.e[3], e1b = r.e[4], e1c = r.e[5], e2a = r.e[6],
                   e2b = r.e[7], e2c = r.e[8];
@@ -361,52 +469,86 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const T
       const float m2 = fmaf(e2a, e2a > 0.0f ? pxhi : pxlo, fmaf(e2b, e2b > 0.0f ? pyhi : pylo, e2c));
       const float zn = fmaf(za, za > 0.0f ? pxlo : pxhi, fmaf(zb, zb > 0.0f ? pylo : pyhi, zc));
       const float zf = fmaf(za, za > 0.0f ? pxhi : pxlo, fmaf(zb, zb > 0.0f ? pyhi : pylo, zc));
-      const uint32_t dn = (uint32_t)fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f);
+      const uint32_t dn = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
       const bool need = bx <= x1 && bx + 3 >= x0 && by <= y1 && by + 3 >= y0 && m0 >= 0.0f && m1 >= 0.0f &&
                         m2 >= 0.0f && zn <= 1.0f && zf >= 0.0f && dn <= lane_far;
       if (!__any(need)) continue;
-      if (!need) continue;
-      const uint32_t prim = flags & 0xFFFFFFu;
-      const uint32_t ridx = qidx[j];
+      if (STATS) st[2]++, st[3] += (unsigned long long)__popcll(__ballot(need));
+      const uint32_t ridx = qe & 0x0FFFFFFFu;
       const float wa = r.wp[0], wb = r.wp[1], wc = r.wp[2];
-      bool updated = false;
+      // Fast path (exact): block fully inside the bbox, whole block inside the depth range and in front
+      // of the eye, texture not alpha-tested.  Edge ties and depth ties are only *detected* here and
+      // replayed through the general path below, so the result is the same as running it everywhere.
+      const float rwn = fmaf(wa, wa > 0.0f ? pxlo : pxhi, fmaf(wb, wb > 0.0f ? pylo : pyhi, wc));
+      const bool fast = need & (bx >= x0) & (bx + 3 <= x1) & (by >= y0) & (by + 3 <= y1) & (zn >= 0.0f) &
+                        (zf <= 1.0f) & (rwn > 0.0f) & ((flags & RASTER_MASKED_ANY) == 0u);
+      bool redo = false, updated = false;
+      if (STATS && __any(fast)) st[4]++, st[5] += (unsigned long long)__popcll(__ballot(fast));
+      if (fast) {
 #pragma unroll
-      for (int ry = 0; ry < 4; ry++) {
-        const int iy = by + ry;
-        const float py = (float)iy + 0.5f;
-        const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
-        const float tz = fmaf(zb, py, zc), tw = fmaf(wb, py, wc);
-        const bool rowin = iy >= y0 && iy <= y1;
+        for (int ry = 0; ry < 4; ry++) {
+          const float py = pylo + (float)ry;
+          const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
+          const float tz = fmaf(zb, py, zc);
 #pragma unroll
-        for (int rx = 0; rx < 4; rx++) {
-          const int k = ry * 4 + rx;
-          const int ix = bx + rx;
-          const float px = (float)ix + 0.5f;
-          const float e0 = fmaf(e0a, px, t0), e1 = fmaf(e1a, px, t1), e2 = fmaf(e2a, px, t2);
-          const bool in0 = (e0 > 0.0f) || (e0 == 0.0f && (flags & (1u << 24)) != 0u);
-          const bool in1 = (e1 > 0.0f) || (e1 == 0.0f && (flags & (1u << 25)) != 0u);
-          const bool in2 = (e2 > 0.0f) || (e2 == 0.0f && (flags & (1u << 26)) != 0u);
-          const float zw = fmaf(za, px, tz);
-          const float rw = fmaf(wa, px, tw);
-          const uint32_t d24 = (uint32_t)fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f);
-          bool pass = rowin && ix >= x0 && ix <= x1 && in0 && in1 && in2 && zw >= 0.0f && zw <= 1.0f && rw > 0.0f &&
-                      d24 <= best_d[k];
-          if (pass && d24 == best_d[k])  // depth tie (rare): the earlier primitive keeps the pixel
-            pass = best_r[k] == NONE || prim < (prec[best_r[k]].r.flags & 0xFFFFFFu);
-          if (pass && (flags & RASTER_MASKED_ANY) != 0u) {  // R6: alpha test before the depth write
-            const ShadeRec &s = q[j].s;
-            const TexelAt t = texel_coords(s, px, tw, fmaf(s.up[1], py, s.up[2]), fmaf(s.vp[1], py, s.vp[2]));
-            // texture rectangle fully opaque: only a coordinate that the float mod pushed just outside
-            // the rectangle can hit a transparent neighbour texel -- fetch only then
-            const bool must_fetch = (flags & RASTER_MASKED_INTERIOR) != 0u || t.ix < (int)s.atlas_u ||
-                                    t.ix >= (int)(s.atlas_u + s.size_x) || t.iy < (int)s.atlas_v ||
-                                    t.iy >= (int)(s.atlas_v + s.size_y);
-            if (must_fetch) pass = (load_texel(lv, RDOOM_KIND_WALL, t.ix, t.iy) & 0x8000u) == 0u;
+          for (int rx = 0; rx < 4; rx++) {
+            const int k = ry * 4 + rx;
+            const float px = pxlo + (float)rx;
+            const float em = fminf(fminf(fmaf(e0a, px, t0), fmaf(e1a, px, t1)), fmaf(e2a, px, t2));
+            const uint32_t d24 = __float2uint_rz(fmaf(fmaf(za, px, tz), 16777215.0f, 0.5f));
+            const bool win = (em > 0.0f) & (d24 < best_d[k]);
+            redo |= (em == 0.0f) | ((em > 0.0f) & (d24 == best_d[k]));
+            best_d[k] = win ? d24 : best_d[k];
+            best_r[k] = win ? ridx : best_r[k];
+            updated |= win;
           }
-          if (pass) {
-            best_d[k] = d24;
-            best_r[k] = ridx;
-            updated = true;
+        }
+      }
+      if (__any(need & (!fast | redo))) {
+        if (STATS) st[6]++, st[7] += (unsigned long long)__popcll(__ballot(need & (!fast | redo)));
+        if (need & (!fast | redo)) {
+          const uint32_t prim = flags & 0xFFFFFFu;
+#pragma unroll
+          for (int ry = 0; ry < 4; ry++) {
+            const int iy = by + ry;
+            const float py = (float)iy + 0.5f;
+            const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
+            const float tz = fmaf(zb, py, zc), tw = fmaf(wb, py, wc);
+            const bool rowin = iy >= y0 && iy <= y1;
+#pragma unroll
+            for (int rx = 0; rx < 4; rx++) {
+              const int ix = bx + rx;
+              const float px = (float)ix + 0.5f;
+              const float e0 = fmaf(e0a, px, t0), e1 = fmaf(e1a, px, t1), e2 = fmaf(e2a, px, t2);
+              const bool in0 = (e0 > 0.0f) | ((e0 == 0.0f) & ((flags & (1u << 24)) != 0u));
+              const bool in1 = (e1 > 0.0f) | ((e1 == 0.0f) & ((flags & (1u << 25)) != 0u));
+              const bool in2 = (e2 > 0.0f) | ((e2 == 0.0f) & ((flags & (1u << 26)) != 0u));
+              const float zw = fmaf(za, px, tz);
+              const float rw = fmaf(wa, px, tw);
+              const uint32_t d24 = __float2uint_rz(fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f));
+              const int k = ry * 4 + rx;
+              const uint32_t bd = best_d[k], br = best_r[k];
+              bool pass = rowin & (ix >= x0) & (ix <= x1) & in0 & in1 & in2 & (zw >= 0.0f) & (zw <= 1.0f) &
+                          (rw > 0.0f) & (d24 <= bd);
+              if (pass && d24 == bd)  // depth tie (rare): the earlier primitive keeps the pixel
+                pass = br == NONE || prim < (prec[br].r.flags & 0xFFFFFFu);
+              if (pass && (flags & RASTER_MASKED_ANY) != 0u) {  // R6: alpha test before the depth write
+                const ShadeRec &sh = q[j].s;
+                const TexelAt t =
+                    texel_coords(sh, px, tw, fmaf(sh.up[1], py, sh.up[2]), fmaf(sh.vp[1], py, sh.vp[2]));
+                // texture rectangle fully opaque: only a coordinate that the float mod pushed just outside
+                // the rectangle can hit a transparent neighbour texel -- fetch only then
+                const bool must_fetch = (flags & RASTER_MASKED_INTERIOR) != 0u || t.ix < (int)sh.atlas_u ||
+                                        t.ix >= (int)(sh.atlas_u + sh.size_x) || t.iy < (int)sh.atlas_v ||
+                                        t.iy >= (int)(sh.atlas_v + sh.size_y);
+                if (must_fetch) pass = (load_texel(lv, RDOOM_KIND_WALL, t.ix, t.iy) & 0x8000u) == 0u;
+              }
+              if (pass) {
+                best_d[k] = d24;
+                best_r[k] = ridx;
+                updated = true;
+              }
+            }
           }
         }
       }
@@ -419,6 +561,8 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const T
     }
     __syncthreads();
   }
+  if (STATS && lane == 0)
+    for (int k = 0; k < 10; k++) atomicAdd(&stats[k], st[k]);
 #pragma unroll
   for (int ry = 0; ry < 4; ry++) {
     const int iy = by + ry;
@@ -561,7 +705,7 @@ struct rdoom_batch {
   uint32_t width = 0, height = 0, max_poses = 0, cap = 0, last_n = 0;
   PoseConst *d_poses = nullptr;
   TriRec *d_recs = nullptr;   // max_poses x cap records (setup -> raster, fragment)
-  uint2 *d_bbox = nullptr;    // packed pixel bboxes of the same records (coarse test)
+  uint4 *d_sorted = nullptr;  // per pose: (bbox, record index, depth bucket) near-to-far (coarse test input)
   uint32_t *d_counts = nullptr, *d_vis = nullptr, *d_prim = nullptr;
   uint8_t *d_fb = nullptr;
   PoseConst *h_poses = nullptr;  // pinned staging for the per-pose constants
@@ -725,7 +869,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
 
 void rdoom_batch_destroy(rdoom_batch *b) {
   if (!b) return;
-  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_bbox, (void *)b->d_counts, (void *)b->d_vis,
+  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_sorted, (void *)b->d_counts, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb})
     if (p) (void)hipFree(p);
   for (auto &e : b->ev)
@@ -751,7 +895,7 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   const size_t npx = (size_t)width * height * max_poses;
   hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_bbox, sizeof(uint2) * (size_t)b->cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_sorted, sizeof(uint4) * (size_t)b->cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, sizeof(uint32_t) * npx);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
@@ -792,19 +936,37 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   if (tm) HIP_TRY(hipEventRecord(b->ev[0], st));
   HIP_TRY(hipMemcpyAsync(b->d_poses, b->h_poses, sizeof(PoseConst) * n, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(b->ev_copy, st));
-  HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
   const int W = (int)b->width, H = (int)b->height;
   if (lv->ntri) {
-    dim3 grid((lv->ntri + 255) / 256, n);
-    hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, st, lv->view, b->d_poses, W, H, kinds_mask, b->d_recs,
-                       b->d_bbox, b->d_counts, b->cap);
+    hipLaunchKernelGGL(setup_kernel, dim3(n), dim3(256), 0, st, lv->view, b->d_poses, W, H, kinds_mask, b->d_recs,
+                       b->d_sorted, b->d_counts, b->cap);
   }
   if (tm) HIP_TRY(hipEventRecord(b->ev[1], st));
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)(tiles_x * tiles_y);
   if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
-  hipLaunchKernelGGL(raster_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs, b->d_bbox,
-                     b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_vis, b->want_prim ? b->d_prim : nullptr);
+  static const bool want_stats = getenv("RDOOM_STATS") != nullptr;
+  if (want_stats) {
+    unsigned long long *d_stats = nullptr, h[10];
+    HIP_TRY(hipMalloc((void **)&d_stats, sizeof h));
+    HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof h, st));
+    hipLaunchKernelGGL(raster_kernel<true>, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs,
+                       b->d_sorted, b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_vis,
+                       b->want_prim ? b->d_prim : nullptr, d_stats);
+    HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
+    (void)hipFree(d_stats);
+    const double waves = (double)nblocks * 4.0;
+    fprintf(stderr,
+            "[rdoom stats] per wave: queue %.1f  quadrant-bbox %.1f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
+            "  general %.1f (lanes %.1f) | coarse tests/block %.0f hits %.1f\n",
+            h[0] / waves, h[1] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
+            h[4] ? (double)h[5] / h[4] : 0.0, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
+            (double)h[8] / (double)nblocks, (double)h[9] / (double)nblocks);
+  } else {
+    hipLaunchKernelGGL(raster_kernel<false>, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs,
+                       b->d_sorted, b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_vis,
+                       b->want_prim ? b->d_prim : nullptr, (unsigned long long *)nullptr);
+  }
   if (tm) HIP_TRY(hipEventRecord(b->ev[2], st));
   const uint64_t n_quads = (uint64_t)n * (uint64_t)H * (uint64_t)(W / 4);
   const uint64_t fblocks = (n_quads + (uint64_t)FRAG_CHUNK * 256 - 1) / ((uint64_t)FRAG_CHUNK * 256);
