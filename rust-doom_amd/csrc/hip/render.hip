@@ -628,9 +628,13 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
   return cmap[rowc * 256 + (int)(texel & 0xFFu)];
 }
 
+// idx / d for idx < 2^24 by multiply-high (m, sh) computed and verified on the host
+__device__ __forceinline__ uint32_t fast_div(uint32_t idx, uint32_t m, uint32_t sh) { return __umulhi(idx, m) >> sh; }
+
 __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
-                                                       const uint32_t *__restrict__ vis, uint64_t n_quads,
+                                                       const uint32_t *__restrict__ vis, uint32_t quads_per_pose,
+                                                       uint32_t quads_per_row, uint32_t div_m, uint32_t div_sh,
                                                        int width, int height, uint8_t *__restrict__ fb) {
   __shared__ uint8_t cmap[32 * 256];
   {
@@ -640,41 +644,35 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
     dst[threadIdx.x + 256] = src[threadIdx.x + 256];
   }
   __syncthreads();
-  const uint32_t quads_per_row = (uint32_t)width >> 2;
-  const uint64_t quads_per_pose = (uint64_t)quads_per_row * (uint64_t)height;
+  const uint32_t pose = blockIdx.y;
+  const PoseConst &pc = poses[pose];
+  const TriRec *prec = recs + (size_t)pose * cap;
+  const uint4 *pvis = reinterpret_cast<const uint4 *>(vis) + (size_t)pose * quads_per_pose;
+  uint32_t *pfb = reinterpret_cast<uint32_t *>(fb) + (size_t)pose * quads_per_pose;
   for (int it = 0; it < FRAG_CHUNK; it++) {
-    const uint64_t qi = ((uint64_t)blockIdx.x * FRAG_CHUNK + (uint64_t)it) * 256ull + threadIdx.x;
-    if (qi >= n_quads) break;
-    const uint32_t pose = (uint32_t)(qi / quads_per_pose);
-    const uint32_t rem = (uint32_t)(qi - (uint64_t)pose * quads_per_pose);
-    const uint32_t row = rem / quads_per_row, qx = rem - row * quads_per_row;
-    const uint4 ids = reinterpret_cast<const uint4 *>(vis)[qi];
+    const uint32_t qi = (blockIdx.x * FRAG_CHUNK + (uint32_t)it) * 256u + threadIdx.x;
+    if (qi >= quads_per_pose) break;
+    const uint32_t row = fast_div(qi, div_m, div_sh), qx = qi - row * quads_per_row;
+    const uint4 ids = pvis[qi];
+    const uint32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
     const float py = (float)row + 0.5f;
     const float px0 = (float)(qx * 4u) + 0.5f;
-    const TriRec *prec = recs + (size_t)pose * cap;
-    uint32_t out = 0;
-    if (ids.x == ids.y && ids.x == ids.z && ids.x == ids.w) {
-      if (ids.x != NONE) {
-        const ShadeRec s = prec[ids.x].s;
-        const float row_w = fmaf(s.wp[1], py, s.wp[2]), row_u = fmaf(s.up[1], py, s.up[2]),
-                    row_v = fmaf(s.vp[1], py, s.vp[2]);
+    uint32_t out = 0, cur_id = NONE;
+    ShadeRec cur;
+    float row_w = 0.0f, row_u = 0.0f, row_v = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-          out |= shade_pixel(lv, cmap, s, px0 + (float)k, py, row_w, row_u, row_v, width, height, poses[pose])
-                 << (8 * k);
+    for (int k = 0; k < 4; k++) {
+      if (id[k] == NONE) continue;
+      if (id[k] != cur_id) {  // neighbouring pixels nearly always share the triangle: one 64-byte load per run
+        cur = prec[id[k]].s;
+        cur_id = id[k];
+        row_w = fmaf(cur.wp[1], py, cur.wp[2]);
+        row_u = fmaf(cur.up[1], py, cur.up[2]);
+        row_v = fmaf(cur.vp[1], py, cur.vp[2]);
       }
-    } else {
-      const uint32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (id[k] == NONE) continue;
-        const ShadeRec s = prec[id[k]].s;
-        out |= shade_pixel(lv, cmap, s, px0 + (float)k, py, fmaf(s.wp[1], py, s.wp[2]), fmaf(s.up[1], py, s.up[2]),
-                           fmaf(s.vp[1], py, s.vp[2]), width, height, poses[pose])
-               << (8 * k);
-      }
+      out |= shade_pixel(lv, cmap, cur, px0 + (float)k, py, row_w, row_u, row_v, width, height, pc) << (8 * k);
     }
-    reinterpret_cast<uint32_t *>(fb)[qi] = out;
+    pfb[qi] = out;
   }
 }
 
@@ -968,10 +966,23 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
                        b->want_prim ? b->d_prim : nullptr, (unsigned long long *)nullptr);
   }
   if (tm) HIP_TRY(hipEventRecord(b->ev[2], st));
-  const uint64_t n_quads = (uint64_t)n * (uint64_t)H * (uint64_t)(W / 4);
-  const uint64_t fblocks = (n_quads + (uint64_t)FRAG_CHUNK * 256 - 1) / ((uint64_t)FRAG_CHUNK * 256);
-  hipLaunchKernelGGL(fragment_kernel, dim3((uint32_t)fblocks), dim3(256), 0, st, lv->view, b->d_recs, b->cap,
-                     b->d_poses, b->d_vis, n_quads, W, H, b->d_fb);
+  const uint32_t qpr = (uint32_t)W / 4u, qpp = qpr * (uint32_t)H;
+  if (qpp >= (1u << 24)) return rdoom::fail(RDOOM_BAD_ARG, "frame too large");
+  // multiply-high divisor for idx / qpr, idx < 2^24 (checked exhaustively at the only places it can fail)
+  if (qpr < 2) return rdoom::fail(RDOOM_BAD_ARG, "width must be at least 8");
+  uint32_t div_sh = 0;
+  while ((2u << div_sh) <= qpr) div_sh++;      // floor(log2(qpr))
+  if ((qpr & (qpr - 1)) == 0) div_sh -= 1;     // power of two: m = 2^31
+  const uint32_t div_m = (uint32_t)((((uint64_t)1 << (32 + div_sh)) + qpr - 1) / qpr);
+  for (uint32_t k = 1; k * qpr <= qpp; k++) {
+    const uint32_t lo = k * qpr - 1, hi = k * qpr;
+    if ((uint32_t)(((uint64_t)lo * div_m) >> 32) >> div_sh != k - 1 ||
+        (hi < qpp && (uint32_t)(((uint64_t)hi * div_m) >> 32) >> div_sh != k))
+      return rdoom::fail(RDOOM_BAD_ARG, "internal: fast_div constants invalid for width %d", W);
+  }
+  const uint32_t fblocks = (qpp + FRAG_CHUNK * 256 - 1) / (FRAG_CHUNK * 256);
+  hipLaunchKernelGGL(fragment_kernel, dim3(fblocks, n), dim3(256), 0, st, lv->view, b->d_recs, b->cap, b->d_poses,
+                     b->d_vis, qpp, qpr, div_m, div_sh, W, H, b->d_fb);
   HIP_TRY(hipGetLastError());
   if (tm) {
     HIP_TRY(hipEventRecord(b->ev[3], st));
