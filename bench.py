@@ -110,13 +110,14 @@ def main():
         batch.render(poses, lights, timed=True)
     barrier()
     t_start = time.perf_counter()
-    frag_ms, raster_ms, setup_ms, vis_tris = [], [], [], 0
+    frag_ms, raster_ms, setup_ms, vis_tris, fixups = [], [], [], 0, 0
     for _ in range(args.steps):
         t = batch.render(poses, lights, timed=True)    # hipEvents on the render stream, per kernel
         frag_ms.append(t['fragment_ms'])
         raster_ms.append(t['raster_ms'])
         setup_ms.append(t['setup_ms'])
         vis_tris = t['visible_triangles']
+        fixups = t['fixup_pixels']
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -163,6 +164,7 @@ def main():
                                    'walls+flats+sky' % (args.poses, args.width, args.height),
                        'poses_per_gpu': args.poses, 'width': args.width, 'height': args.height,
                        'visible_triangles_per_pose': round(vis_tris / args.poses, 1),
+                       'alpha_leak_fixup_pixels_per_step': fixups,
                        'kernels_ms': {'setup': round(float(np.mean(setup_ms)), 3),
                                       'raster': round(float(np.mean(raster_ms)), 3), 'fragment': round(frag, 3)},
                        'parallelism': 'pose-sharded x%d, no collective' % world},

@@ -125,6 +125,7 @@ typedef struct rdoom_timings {
   float setup_ms, raster_ms, fragment_ms, total_ms;
   uint64_t pixels; /* n_poses * width * height of that render */
   uint64_t visible_triangles;
+  uint64_t fixup_pixels; /* pixels re-resolved by the alpha-leak fixup kernel (normally a handful) */
 } rdoom_timings;
 
 /* counters logged by the reference at level build (game/src/level.rs:384-422) */

@@ -57,7 +57,8 @@ class LevelDesc(ctypes.Structure):
 
 class Timings(ctypes.Structure):
     _fields_ = [('setup_ms', ctypes.c_float), ('raster_ms', ctypes.c_float), ('fragment_ms', ctypes.c_float),
-                ('total_ms', ctypes.c_float), ('pixels', ctypes.c_uint64), ('visible_triangles', ctypes.c_uint64)]
+                ('total_ms', ctypes.c_float), ('pixels', ctypes.c_uint64), ('visible_triangles', ctypes.c_uint64),
+                ('fixup_pixels', ctypes.c_uint64)]
 
 
 class Counters(ctypes.Structure):

@@ -8,6 +8,7 @@
 // Built with -ffp-contract=off: a*b+c is never fused unless written as fmaf.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -308,6 +309,141 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
   }
 }
 
+// Exact rejection of a triangle against the four 32x32 quadrants of the 64x64 tile at (tx0, ty0):
+// fmaf is monotone in each argument, so the extreme of a *computed* edge function / depth plane over a
+// rectangle of pixel centres is attained at a corner.  Bit q of the result = "may touch quadrant q".
+__device__ __forceinline__ uint32_t tile_quadrant_mask(const uint4 c0, const uint4 c1, const uint4 c2, int x0, int y0,
+                                                       int x1, int y1, int tx0, int ty0) {
+  const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
+              e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
+              e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x),
+              za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
+  uint32_t qm = 0;
+#pragma unroll
+  for (int qd = 0; qd < 4; qd++) {
+    const int rx0 = tx0 + (qd & 1) * 32, ry0 = ty0 + (qd >> 1) * 32;
+    const float xl = (float)rx0 + 0.5f, xh = (float)rx0 + 31.5f, yl = (float)ry0 + 0.5f, yh = (float)ry0 + 31.5f;
+    const float m0 = fmaf(e0a, e0a > 0.0f ? xh : xl, fmaf(e0b, e0b > 0.0f ? yh : yl, e0c));
+    const float m1 = fmaf(e1a, e1a > 0.0f ? xh : xl, fmaf(e1b, e1b > 0.0f ? yh : yl, e1c));
+    const float m2 = fmaf(e2a, e2a > 0.0f ? xh : xl, fmaf(e2b, e2b > 0.0f ? yh : yl, e2c));
+    const float zn = fmaf(za, za > 0.0f ? xl : xh, fmaf(zb, zb > 0.0f ? yl : yh, zc));
+    const float zf = fmaf(za, za > 0.0f ? xh : xl, fmaf(zb, zb > 0.0f ? yh : yl, zc));
+    const bool ok = (x0 <= rx0 + 31) & (x1 >= rx0) & (y0 <= ry0 + 31) & (y1 >= ry0) & (m0 >= 0.0f) & (m1 >= 0.0f) &
+                    (m2 >= 0.0f) & (zn <= 1.0f) & (zf >= 0.0f);
+    qm |= ok ? (1u << qd) : 0u;
+  }
+  return qm;
+}
+
+// Same corner argument for the whole 64x64 tile: false = no pixel of the tile can be covered.
+__device__ __forceinline__ bool tile_may_touch(const uint4 c0, const uint4 c1, const uint4 c2, int tx0, int ty0) {
+  const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
+              e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
+              e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x),
+              za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
+  const float xl = (float)tx0 + 0.5f, xh = (float)tx0 + 63.5f, yl = (float)ty0 + 0.5f, yh = (float)ty0 + 63.5f;
+  const float m0 = fmaf(e0a, e0a > 0.0f ? xh : xl, fmaf(e0b, e0b > 0.0f ? yh : yl, e0c));
+  const float m1 = fmaf(e1a, e1a > 0.0f ? xh : xl, fmaf(e1b, e1b > 0.0f ? yh : yl, e1c));
+  const float m2 = fmaf(e2a, e2a > 0.0f ? xh : xl, fmaf(e2b, e2b > 0.0f ? yh : yl, e2c));
+  const float zn = fmaf(za, za > 0.0f ? xl : xh, fmaf(zb, zb > 0.0f ? yl : yh, zc));
+  const float zf = fmaf(za, za > 0.0f ? xh : xl, fmaf(zb, zb > 0.0f ? yh : yl, zc));
+  return (m0 >= 0.0f) & (m1 >= 0.0f) & (m2 >= 0.0f) & (zn <= 1.0f) & (zf >= 0.0f);
+}
+
+// =================================================================================================
+// Kernel 1b: binning.  One workgroup per pose turns the near-to-far triangle list into per-tile
+// lists: each wave takes a triangle, its 64 lanes take 64 tiles of the bbox's tile rectangle and run
+// the exact quadrant test; count -> scan -> fill.  The rasteriser then starts from a short list
+// (a handful of entries per tile) instead of scanning every visible triangle of the pose.
+// entry = record index | quadrant mask << 28.  If a pose needs more than entry_cap entries (or the
+// frame has more than MAX_TILES tiles) its overflow flag is set and the rasteriser scans instead.
+// =================================================================================================
+constexpr uint32_t MAX_TILES = 8192;
+
+constexpr int BIN_THREADS = 1024;
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restrict__ recs, const uint4 *__restrict__ sorted,
+                                                  const uint32_t *__restrict__ counts, uint32_t cap, int tiles_x,
+                                                  int tiles_y, uint2 *__restrict__ tile_hdr,
+                                                  uint32_t *__restrict__ entries, uint32_t entry_cap,
+                                                  uint32_t *__restrict__ overflow) {
+  __shared__ uint32_t tile_cnt[MAX_TILES];
+  __shared__ uint32_t tile_off[MAX_TILES];
+  __shared__ uint32_t scan_tmp[256];
+  const uint32_t pose = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr uint32_t NW = BIN_THREADS / 64;
+  const uint32_t T = (uint32_t)(tiles_x * tiles_y);
+  if (T > MAX_TILES) {
+    if (tid == 0) overflow[pose] = 1u;
+    return;
+  }
+  const TriRec *prec = recs + (size_t)pose * cap;
+  const uint4 *psorted = sorted + (size_t)pose * cap;
+  uint2 *hdr = tile_hdr + (size_t)pose * T;
+  uint32_t *pent = entries + (size_t)pose * entry_cap;
+  const uint32_t n = counts[pose];
+  for (uint32_t i = tid; i < T; i += BIN_THREADS) tile_cnt[i] = 0;
+  __syncthreads();
+  for (int pass = 0; pass < 2; pass++) {
+    for (uint32_t si = (uint32_t)wave; si < n; si += NW) {
+      const uint4 ent = psorted[si];  // wave-uniform
+      const int x0 = (int)(ent.x & 0xFFFFu), y0 = (int)(ent.x >> 16), x1 = (int)(ent.y & 0xFFFFu),
+                y1 = (int)(ent.y >> 16);
+      const int tx0 = x0 >> 6, ty0 = y0 >> 6, ntx = (x1 >> 6) - tx0 + 1, nt = ntx * ((y1 >> 6) - ty0 + 1);
+      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[ent.z]);
+      const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2];
+      const float inv_ntx = 1.0f / (float)ntx;
+      for (int tb = 0; tb < nt; tb += 64) {
+        const int t = tb + lane;
+        if (t < nt) {
+          const int ty = (int)(((float)t + 0.5f) * inv_ntx), tx = t - ty * ntx;  // t / ntx (t < 8192: exact)
+          uint32_t qm = 0;
+          if (tile_may_touch(c0, c1, c2, (tx0 + tx) * 64, (ty0 + ty) * 64))
+            qm = tile_quadrant_mask(c0, c1, c2, x0, y0, x1, y1, (tx0 + tx) * 64, (ty0 + ty) * 64);
+          if (qm) {
+            const uint32_t tile = (uint32_t)((ty0 + ty) * tiles_x + tx0 + tx);
+            if (pass == 0) {
+              atomicAdd(&tile_cnt[tile], 1u);
+            } else {
+              const uint32_t pos = atomicAdd(&tile_off[tile], 1u);
+              if (pos < entry_cap) pent[pos] = ent.z | (qm << 28);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (pass == 1) break;
+    // exclusive scan of tile_cnt -> tile_off (first 256 threads own T/256 consecutive tiles each); headers out
+    const uint32_t per = (T + 255u) / 256u, lo = min((uint32_t)tid * per, T), hi = min(lo + per, T);
+    uint32_t sum = 0;
+    if (tid < 256) {
+      for (uint32_t i = lo; i < hi; i++) sum += tile_cnt[i];
+      scan_tmp[tid] = sum;
+    }
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const uint32_t v = (tid < 256 && tid >= d) ? scan_tmp[tid - d] : 0u;
+      __syncthreads();
+      if (tid < 256) scan_tmp[tid] += v;
+      __syncthreads();
+    }
+    const uint32_t total = scan_tmp[255];
+    if (tid < 256) {
+      uint32_t run = scan_tmp[tid] - sum;
+      for (uint32_t i = lo; i < hi; i++) {
+        tile_off[i] = run;
+        hdr[i] = make_uint2(run, tile_cnt[i]);
+        run += tile_cnt[i];
+      }
+    }
+    if (tid == 0) overflow[pose] = total > entry_cap ? 1u : 0u;
+    __syncthreads();
+    if (total > entry_cap) return;
+  }
+}
+
 // F1..F3: perspective-correct tile coordinates -> atlas texel coordinates (shared by the alpha test
 // R6 and the fragment stage).  `row_u`/`row_v`/`row_w` are fmaf(B, py, C) of the three planes.
 struct TexelAt {
@@ -361,12 +497,14 @@ __device__ __forceinline__ uint32_t load_texel(const DeviceLevelView &lv, uint32
 // XCD's L2.
 // =================================================================================================
 template <bool STATS>
-__global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+__global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                      const uint4 *__restrict__ sorted,
                                                      const uint32_t *__restrict__ counts, uint32_t cap,
                                                      uint32_t n_poses, int width, int height, int tiles_x,
-                                                     int tiles_y, uint32_t *__restrict__ vis,
-                                                     uint32_t *__restrict__ prim_out,
+                                                     int tiles_y, const uint2 *__restrict__ tile_hdr,
+                                                     const uint32_t *__restrict__ entries, uint32_t entry_cap,
+                                                     const uint32_t *__restrict__ overflow,
+                                                     uint32_t *__restrict__ vis, uint32_t *__restrict__ prim_out,
                                                      unsigned long long *__restrict__ stats) {
   // STATS (debug builds of the launch only): [0] queue entries seen by waves, [1] past the quadrant bbox,
   // [2] past the lane-level rejection (__any(need)), [3] lanes needing, [4] fast bodies, [5] lanes in fast
@@ -393,14 +531,21 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const T
     best_r[k] = NONE;
   }
   uint32_t lane_far = NONE;  // max of best_d: the farthest depth this lane still holds
-  const uint32_t count = counts[pose];
   const TriRec *prec = recs + (size_t)pose * cap;
   const uint4 *psorted = sorted + (size_t)pose * cap;
+  const bool binned = overflow[pose] == 0u;  // the pose's per-tile lists are complete
+  const uint2 hdr = binned ? tile_hdr[(size_t)pose * T + tile] : make_uint2(0u, counts[pose]);
+  const uint32_t *pent = entries + (size_t)pose * entry_cap + hdr.x;
+  const uint32_t count = hdr.y;
   for (uint32_t base = 0; base < count; base += 256u) {
-    // ---- coarse: one triangle per lane ------------------------------------------------------------
-    // (a) packed bbox vs tile; (b) for the survivors an EXACT per-quadrant test from the record's edge and
-    // depth planes (corner evaluation, see above) -- triangles that cross the eye plane carry a
-    // full-screen bbox, so (b) is what keeps the queues short; (c) ordered compaction + staging.
+    uint32_t n;
+    if (binned) {
+      n = min(256u, count - base);
+      if ((uint32_t)tid < n) qidx[tid] = pent[base + (uint32_t)tid];
+      __syncthreads();
+    } else {
+    // ---- fallback coarse scan (pose without complete bins): one triangle per lane, packed bbox vs tile,
+    // exact quadrant test for the survivors, ordered compaction
     const uint32_t i = base + (uint32_t)tid;
     uint32_t qm = 0, rec_index = 0;
     if (i < count) {
@@ -409,24 +554,7 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const T
       const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
       if (x0 <= tx0 + TILE_W - 1 && x1 >= tx0 && y0 <= ty0 + TILE_H - 1 && y1 >= ty0) {
         const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[rec_index]);
-        const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2];  // e[0..8], zp[0..2]
-        const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
-                    e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
-                    e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x),
-                    za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
-#pragma unroll
-        for (int qd = 0; qd < 4; qd++) {
-          const int rx0 = tx0 + (qd & 1) * 32, ry0 = ty0 + (qd >> 1) * 32;
-          const float xl = (float)rx0 + 0.5f, xh = (float)rx0 + 31.5f, yl = (float)ry0 + 0.5f, yh = (float)ry0 + 31.5f;
-          const float m0 = fmaf(e0a, e0a > 0.0f ? xh : xl, fmaf(e0b, e0b > 0.0f ? yh : yl, e0c));
-          const float m1 = fmaf(e1a, e1a > 0.0f ? xh : xl, fmaf(e1b, e1b > 0.0f ? yh : yl, e1c));
-          const float m2 = fmaf(e2a, e2a > 0.0f ? xh : xl, fmaf(e2b, e2b > 0.0f ? yh : yl, e2c));
-          const float zn = fmaf(za, za > 0.0f ? xl : xh, fmaf(zb, zb > 0.0f ? yl : yh, zc));
-          const float zf = fmaf(za, za > 0.0f ? xh : xl, fmaf(zb, zb > 0.0f ? yh : yl, zc));
-          const bool ok = (x0 <= rx0 + 31) & (x1 >= rx0) & (y0 <= ry0 + 31) & (y1 >= ry0) & (m0 >= 0.0f) &
-                          (m1 >= 0.0f) & (m2 >= 0.0f) & (zn <= 1.0f) & (zf >= 0.0f);
-          qm |= ok ? (1u << qd) : 0u;
-        }
+        qm = tile_quadrant_mask(rp[0], rp[1], rp[2], x0, y0, x1, y1, tx0, ty0);
       }
     }
     const bool hit = qm != 0u;
@@ -434,7 +562,8 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const T
     if (STATS) st[8] += (unsigned long long)__popcll(__ballot(i < count)), st[9] += (unsigned long long)__popcll(hm);
     if (lane == 0) wcnt[wave] = (uint32_t)__popcll(hm);
     __syncthreads();
-    uint32_t off = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull)), n = 0;
+    uint32_t off = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+    n = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       const uint32_t c = wcnt[w];
@@ -443,6 +572,7 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const T
     }
     if (hit) qidx[off] = rec_index | (qm << 28);
     __syncthreads();
+    }
     // cooperative staging: 9 x 16-byte chunks per record
     for (uint32_t c = (uint32_t)tid; c < n * 9u; c += 256u) {
       const uint32_t e = c / 9u, k = c - e * 9u;
@@ -477,11 +607,14 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceLevelView lv, const T
       const uint32_t ridx = qe & 0x0FFFFFFFu;
       const float wa = r.wp[0], wb = r.wp[1], wc = r.wp[2];
       // Fast path (exact): block fully inside the bbox, whole block inside the depth range and in front
-      // of the eye, texture not alpha-tested.  Edge ties and depth ties are only *detected* here and
+      // of the eye, texture rectangle fully opaque.  Edge ties and depth ties are only *detected* here and
       // replayed through the general path below, so the result is the same as running it everywhere.
+      // A texture whose only transparent texels lie in the one-texel ring around its rectangle
+      // (RASTER_MASKED_BORDER) is treated as opaque here; the rare pixel whose float mod lands on the ring
+      // is caught by the fragment kernel (it sees a transparent texel) and re-resolved by fixup_kernel.
       const float rwn = fmaf(wa, wa > 0.0f ? pxlo : pxhi, fmaf(wb, wb > 0.0f ? pylo : pyhi, wc));
       const bool fast = need & (bx >= x0) & (bx + 3 <= x1) & (by >= y0) & (by + 3 <= y1) & (zn >= 0.0f) &
-                        (zf <= 1.0f) & (rwn > 0.0f) & ((flags & RASTER_MASKED_ANY) == 0u);
+                        (zf <= 1.0f) & (rwn > 0.0f) & ((flags & RASTER_MASKED_INTERIOR) == 0u);
       bool redo = false, updated = false;
       if (STATS && __any(fast)) st[4]++, st[5] += (unsigned long long)__popcll(__ballot(fast));
       if (fast) {
@@ -614,6 +747,8 @@ __device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const u
   return cmap[texel & 0xFFu];
 }
 
+// returns the palette index, or 0x100 | index when the winning wall fragment's texel is transparent (the
+// rasteriser treated a border-masked texture as opaque and the coordinate leaked onto the ring)
 __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const uint8_t *cmap, const ShadeRec &s,
                                                 float px, float py, float row_w, float row_u, float row_v,
                                                 int width, int height, const PoseConst &pc) {
@@ -621,6 +756,7 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
   if (kind == RDOOM_KIND_SKY) return shade_sky(lv, cmap, px, py, width, height, pc.vr0, pc.vr1);
   const TexelAt t = texel_coords(s, px, row_w, row_u, row_v);
   const uint32_t texel = load_texel(lv, kind, t.ix, t.iy);
+  if (kind == RDOOM_KIND_WALL && (texel & 0x8000u)) return 0x100u;
   const float dist_term = fminf(1.0f, 1.0f - 0.9f / (t.dist + 0.9f));
   const float light = s.light * 2.0f - dist_term;
   const float tt = (1.0f - light) * 32.0f;
@@ -635,7 +771,9 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
                                                        const uint32_t *__restrict__ vis, uint32_t quads_per_pose,
                                                        uint32_t quads_per_row, uint32_t div_m, uint32_t div_sh,
-                                                       int width, int height, uint8_t *__restrict__ fb) {
+                                                       int width, int height, uint8_t *__restrict__ fb,
+                                                       uint32_t *__restrict__ fix_count, uint2 *__restrict__ fix_list,
+                                                       uint32_t fix_cap, uint32_t debug_leak_mod) {
   __shared__ uint8_t cmap[32 * 256];
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(lv.colormap);
@@ -670,9 +808,110 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
         row_u = fmaf(cur.up[1], py, cur.up[2]);
         row_v = fmaf(cur.vp[1], py, cur.vp[2]);
       }
-      out |= shade_pixel(lv, cmap, cur, px0 + (float)k, py, row_w, row_u, row_v, width, height, pc) << (8 * k);
+      const uint32_t c = shade_pixel(lv, cmap, cur, px0 + (float)k, py, row_w, row_u, row_v, width, height, pc);
+      // debug_leak_mod != 0 (tests only): pretend every n-th pixel leaked, so fixup_kernel's general rule
+      // is exercised on ordinary pixels too -- the output must not change
+      const bool forced = debug_leak_mod != 0u && ((row * quads_per_row + qx) * 4u + (uint32_t)k) % debug_leak_mod == 0u;
+      if ((c & 0x100u) || forced) {  // rare: alpha leak, queue the pixel for exact re-resolution
+        const uint32_t slot = atomicAdd(fix_count, 1u);
+        if (slot < fix_cap) fix_list[slot] = make_uint2(pose, (row * quads_per_row + qx) * 4u + (uint32_t)k);
+      }
+      out |= (c & 0xFFu) << (8 * k);
     }
     pfb[qi] = out;
+  }
+}
+
+// =================================================================================================
+// Kernel 4: fixup.  Re-resolves the (rare) pixels queued by the fragment kernel with the general rule
+// R1..R6 applied to every candidate of the pixel's tile: lanes = candidates, lexicographic wave-min of
+// (d24, primitive), then the winner is shaded.  One wave per queued pixel; the list is usually empty.
+// =================================================================================================
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_xor(v, d);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+                                                    const uint4 *__restrict__ sorted,
+                                                    const uint32_t *__restrict__ counts, uint32_t cap,
+                                                    const PoseConst *__restrict__ poses, int width, int height,
+                                                    int tiles_x, int tiles_y, const uint2 *__restrict__ tile_hdr,
+                                                    const uint32_t *__restrict__ entries, uint32_t entry_cap,
+                                                    const uint32_t *__restrict__ overflow,
+                                                    const uint32_t *__restrict__ fix_count,
+                                                    const uint2 *__restrict__ fix_list, uint32_t fix_cap,
+                                                    uint32_t *__restrict__ vis, uint32_t *__restrict__ prim_out,
+                                                    uint8_t *__restrict__ fb, uint32_t *__restrict__ error_flag) {
+  const uint32_t total = *fix_count;
+  if (total > fix_cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *error_flag = 1u;
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave_id = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+  for (uint32_t item = wave_id; item < total; item += n_waves) {
+    const uint2 it = fix_list[item];
+    const uint32_t pose = it.x, pix = it.y;
+    const int iy = (int)(pix / (uint32_t)width), ix = (int)(pix - (uint32_t)iy * (uint32_t)width);
+    const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
+    const TriRec *prec = recs + (size_t)pose * cap;
+    const bool binned = overflow[pose] == 0u;
+    const uint32_t T = (uint32_t)(tiles_x * tiles_y), tile = (uint32_t)((iy >> 6) * tiles_x + (ix >> 6));
+    const uint2 hdr = binned ? tile_hdr[(size_t)pose * T + tile] : make_uint2(0u, counts[pose]);
+    unsigned long long best = ~0ull;
+    uint32_t best_rec = NONE;
+    for (uint32_t base = 0; base < hdr.y; base += 64u) {
+      const uint32_t e = base + lane;
+      unsigned long long key = ~0ull;
+      uint32_t rec = NONE;
+      if (e < hdr.y) {
+        rec = binned ? (entries[(size_t)pose * entry_cap + hdr.x + e] & 0x0FFFFFFFu) : sorted[(size_t)pose * cap + e].z;
+        const RasterRec r = prec[rec].r;
+        const int x0 = (int)(r.bb0 & 0xFFFFu), y0 = (int)(r.bb0 >> 16), x1 = (int)(r.bb1 & 0xFFFFu),
+                  y1 = (int)(r.bb1 >> 16);
+        const float e0 = fmaf(r.e[0], px, fmaf(r.e[1], py, r.e[2])), e1 = fmaf(r.e[3], px, fmaf(r.e[4], py, r.e[5])),
+                    e2 = fmaf(r.e[6], px, fmaf(r.e[7], py, r.e[8]));
+        const bool in0 = (e0 > 0.0f) | ((e0 == 0.0f) & ((r.flags & (1u << 24)) != 0u));
+        const bool in1 = (e1 > 0.0f) | ((e1 == 0.0f) & ((r.flags & (1u << 25)) != 0u));
+        const bool in2 = (e2 > 0.0f) | ((e2 == 0.0f) & ((r.flags & (1u << 26)) != 0u));
+        const float zw = fmaf(r.zp[0], px, fmaf(r.zp[1], py, r.zp[2]));
+        const float rw = fmaf(r.wp[0], px, fmaf(r.wp[1], py, r.wp[2]));
+        bool pass = (ix >= x0) & (ix <= x1) & (iy >= y0) & (iy <= y1) & in0 & in1 & in2 & (zw >= 0.0f) & (zw <= 1.0f) &
+                    (rw > 0.0f);
+        if (pass && (r.flags & RASTER_MASKED_ANY) != 0u) {
+          const ShadeRec sh = prec[rec].s;
+          const TexelAt t = texel_coords(sh, px, fmaf(sh.wp[1], py, sh.wp[2]), fmaf(sh.up[1], py, sh.up[2]),
+                                         fmaf(sh.vp[1], py, sh.vp[2]));
+          pass = (load_texel(lv, RDOOM_KIND_WALL, t.ix, t.iy) & 0x8000u) == 0u;
+        }
+        if (pass) {
+          const uint32_t d24 = __float2uint_rz(fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f));
+          key = ((unsigned long long)d24 << 32) | (unsigned long long)(r.flags & 0xFFFFFFu);
+        }
+      }
+      const unsigned long long m = wave_min_u64(key);
+      if (m < best) {
+        best = m;
+        const unsigned long long who = __ballot(key == m);
+        best_rec = __shfl(rec, __ffsll((long long)who) - 1);
+      }
+    }
+    if (lane == 0) {
+      const size_t o = ((size_t)pose * (size_t)height + (size_t)iy) * (size_t)width + (size_t)ix;
+      uint32_t colour = 0;
+      if (best_rec != NONE) {
+        const ShadeRec sh = prec[best_rec].s;
+        colour = shade_pixel(lv, lv.colormap, sh, px, py, fmaf(sh.wp[1], py, sh.wp[2]), fmaf(sh.up[1], py, sh.up[2]),
+                             fmaf(sh.vp[1], py, sh.vp[2]), width, height, poses[pose]) & 0xFFu;
+      }
+      vis[o] = best_rec;
+      if (prim_out) prim_out[o] = best_rec == NONE ? NONE : (uint32_t)(best & 0xFFFFFFull);
+      fb[o] = (uint8_t)colour;
+    }
   }
 }
 
@@ -704,6 +943,13 @@ struct rdoom_batch {
   PoseConst *d_poses = nullptr;
   TriRec *d_recs = nullptr;   // max_poses x cap records (setup -> raster, fragment)
   uint4 *d_sorted = nullptr;  // per pose: (bbox, record index, depth bucket) near-to-far (coarse test input)
+  uint2 *d_tile_hdr = nullptr;     // per (pose, tile): (first entry, entry count)
+  uint32_t *d_entries = nullptr;   // per pose: entry_cap tile-list entries (record index | quadrant mask << 28)
+  uint32_t *d_overflow = nullptr;  // per pose: 1 = bins incomplete, rasteriser scans the sorted list
+  uint32_t entry_cap = 0, n_tiles = 0;
+  uint32_t *d_fix_count = nullptr;  // [0] = queued pixels, [1] = error flag (fixup list overflow)
+  uint2 *d_fix_list = nullptr;
+  uint32_t fix_cap = 1u << 20;
   uint32_t *d_counts = nullptr, *d_vis = nullptr, *d_prim = nullptr;
   uint8_t *d_fb = nullptr;
   PoseConst *h_poses = nullptr;  // pinned staging for the per-pose constants
@@ -867,7 +1113,8 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
 
 void rdoom_batch_destroy(rdoom_batch *b) {
   if (!b) return;
-  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_sorted, (void *)b->d_counts, (void *)b->d_vis,
+  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries,
+                  (void *)b->d_overflow, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb})
     if (p) (void)hipFree(p);
   for (auto &e : b->ev)
@@ -894,6 +1141,13 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_sorted, sizeof(uint4) * (size_t)b->cap * max_poses);
+  b->n_tiles = ((width + TILE_W - 1) / TILE_W) * ((height + TILE_H - 1) / TILE_H);
+  b->entry_cap = std::max<uint32_t>(65536u, 32u * b->n_tiles);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_tile_hdr, sizeof(uint2) * (size_t)b->n_tiles * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_entries, sizeof(uint32_t) * (size_t)b->entry_cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_overflow, sizeof(uint32_t) * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_count, 2 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_list, sizeof(uint2) * (size_t)b->fix_cap);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, sizeof(uint32_t) * npx);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
@@ -939,8 +1193,16 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     hipLaunchKernelGGL(setup_kernel, dim3(n), dim3(256), 0, st, lv->view, b->d_poses, W, H, kinds_mask, b->d_recs,
                        b->d_sorted, b->d_counts, b->cap);
   }
-  if (tm) HIP_TRY(hipEventRecord(b->ev[1], st));
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+  static const bool no_bins = getenv("RDOOM_NO_BINS") != nullptr;  // debug: exercise the fallback scan
+  if (lv->ntri && !no_bins) {
+    hipLaunchKernelGGL(bin_kernel, dim3(n), dim3(BIN_THREADS), 0, st, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x,
+                       tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow);
+  } else {
+    HIP_TRY(hipMemsetAsync(b->d_overflow, 0xFF, sizeof(uint32_t) * n, st));
+    if (!lv->ntri) HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
+  }
+  if (tm) HIP_TRY(hipEventRecord(b->ev[1], st));
   const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)(tiles_x * tiles_y);
   if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
   static const bool want_stats = getenv("RDOOM_STATS") != nullptr;
@@ -949,8 +1211,8 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     HIP_TRY(hipMalloc((void **)&d_stats, sizeof h));
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof h, st));
     hipLaunchKernelGGL(raster_kernel<true>, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs,
-                       b->d_sorted, b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_vis,
-                       b->want_prim ? b->d_prim : nullptr, d_stats);
+                       b->d_sorted, b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
+                       b->entry_cap, b->d_overflow, b->d_vis, b->want_prim ? b->d_prim : nullptr, d_stats);
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     (void)hipFree(d_stats);
     const double waves = (double)nblocks * 4.0;
@@ -962,8 +1224,9 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
             (double)h[8] / (double)nblocks, (double)h[9] / (double)nblocks);
   } else {
     hipLaunchKernelGGL(raster_kernel<false>, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs,
-                       b->d_sorted, b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_vis,
-                       b->want_prim ? b->d_prim : nullptr, (unsigned long long *)nullptr);
+                       b->d_sorted, b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
+                       b->entry_cap, b->d_overflow, b->d_vis, b->want_prim ? b->d_prim : nullptr,
+                       (unsigned long long *)nullptr);
   }
   if (tm) HIP_TRY(hipEventRecord(b->ev[2], st));
   const uint32_t qpr = (uint32_t)W / 4u, qpp = qpr * (uint32_t)H;
@@ -981,8 +1244,15 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
       return rdoom::fail(RDOOM_BAD_ARG, "internal: fast_div constants invalid for width %d", W);
   }
   const uint32_t fblocks = (qpp + FRAG_CHUNK * 256 - 1) / (FRAG_CHUNK * 256);
+  static const uint32_t debug_leak_mod = getenv("RDOOM_DEBUG_LEAK_MOD") ? (uint32_t)atoi(getenv("RDOOM_DEBUG_LEAK_MOD")) : 0u;
+  HIP_TRY(hipMemsetAsync(b->d_fix_count, 0, 2 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(fragment_kernel, dim3(fblocks, n), dim3(256), 0, st, lv->view, b->d_recs, b->cap, b->d_poses,
-                     b->d_vis, qpp, qpr, div_m, div_sh, W, H, b->d_fb);
+                     b->d_vis, qpp, qpr, div_m, div_sh, W, H, b->d_fb, b->d_fix_count, b->d_fix_list, b->fix_cap,
+                     debug_leak_mod);
+  hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap,
+                     b->d_poses, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow,
+                     b->d_fix_count, b->d_fix_list, b->fix_cap, b->d_vis, b->want_prim ? b->d_prim : nullptr, b->d_fb,
+                     b->d_fix_count + 1);
   HIP_TRY(hipGetLastError());
   if (tm) {
     HIP_TRY(hipEventRecord(b->ev[3], st));
@@ -996,6 +1266,10 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     HIP_TRY(hipMemcpy(counts.data(), b->d_counts, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
     tm->visible_triangles = 0;
     for (uint32_t c : counts) tm->visible_triangles += c;
+    uint32_t fix[2] = {0, 0};
+    HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
+    tm->fixup_pixels = fix[0];
+    if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
   }
   return RDOOM_OK;
 }
@@ -1023,6 +1297,9 @@ rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *b, uint32_t first, uint32
   if ((uint64_t)first + count > b->last_n) return rdoom::fail(RDOOM_BAD_ARG, "frame range outside the last render");
   const size_t frame = (size_t)b->width * b->height;
   HIP_TRY(hipDeviceSynchronize());
+  uint32_t fix[2] = {0, 0};
+  HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
+  if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
   HIP_TRY(hipMemcpy(host_out, b->d_fb + frame * first, frame * count, hipMemcpyDeviceToHost));
   return RDOOM_OK;
 }
