@@ -219,13 +219,10 @@ static uint8_t shade_sky(const OracleLevel *L, float px, float py, int width, in
 
 /* Renders one pose.  out_fb: height*width bytes, row 0 = bottom (glReadPixels order).
  * out_prim (optional): winning primitive id per pixel or NO_PRIM.  kinds_mask: bit k enables KIND k. */
-int oracle_render(const OracleLevel *L, const float *modelview, const float *projection, float time,
-                  const uint8_t *lights, int width, int height, uint32_t kinds_mask, uint8_t *out_fb,
-                  uint32_t *out_prim) {
+static int render_with_scratch(const OracleLevel *L, const float *modelview, const float *projection, float time,
+                               const uint8_t *lights, int width, int height, uint32_t kinds_mask, uint8_t *out_fb,
+                               uint32_t *out_prim, uint32_t *depth, uint32_t *prim) {
   size_t npx = (size_t)width * (size_t)height;
-  uint32_t *depth = (uint32_t *)malloc(npx * sizeof(uint32_t));
-  uint32_t *prim = (uint32_t *)malloc(npx * sizeof(uint32_t));
-  if (!depth || !prim) return -1;
   for (size_t i = 0; i < npx; i++) {
     depth[i] = 0xFFFFFFFFu;
     prim[i] = NO_PRIM;
@@ -301,20 +298,38 @@ int oracle_render(const OracleLevel *L, const float *modelview, const float *pro
     }
   }
   if (out_prim) memcpy(out_prim, prim, npx * sizeof(uint32_t));
+  return 0;
+}
+
+int oracle_render(const OracleLevel *L, const float *modelview, const float *projection, float time,
+                  const uint8_t *lights, int width, int height, uint32_t kinds_mask, uint8_t *out_fb,
+                  uint32_t *out_prim) {
+  size_t npx = (size_t)width * (size_t)height;
+  uint32_t *depth = (uint32_t *)malloc(npx * sizeof(uint32_t));
+  uint32_t *prim = (uint32_t *)malloc(npx * sizeof(uint32_t));
+  int rc = -1;
+  if (depth && prim)
+    rc = render_with_scratch(L, modelview, projection, time, lights, width, height, kinds_mask, out_fb, out_prim, depth,
+                             prim);
   free(depth);
   free(prim);
-  return 0;
+  return rc;
 }
 
 /* Renders a batch of poses with `threads`-way pose parallelism left to the caller (ctypes releases the
  * GIL); poses: n * (16 modelview + 16 projection + 1 time) floats; lights: n * 256 bytes. */
 int oracle_render_batch(const OracleLevel *L, const float *poses, const uint8_t *lights, int n, int width, int height,
                         uint32_t kinds_mask, uint8_t *out_fb) {
-  for (int i = 0; i < n; i++) {
+  size_t npx = (size_t)width * (size_t)height;
+  uint32_t *depth = (uint32_t *)malloc(npx * sizeof(uint32_t)); /* one scratch pair per caller thread */
+  uint32_t *prim = (uint32_t *)malloc(npx * sizeof(uint32_t));
+  int rc = (depth && prim) ? 0 : -1;
+  for (int i = 0; i < n && !rc; i++) {
     const float *p = poses + (size_t)i * 33;
-    int rc = oracle_render(L, p, p + 16, p[32], lights + (size_t)i * 256, width, height, kinds_mask,
-                           out_fb + (size_t)i * (size_t)width * (size_t)height, 0);
-    if (rc) return rc;
+    rc = render_with_scratch(L, p, p + 16, p[32], lights + (size_t)i * 256, width, height, kinds_mask,
+                             out_fb + (size_t)i * npx, 0, depth, prim);
   }
-  return 0;
+  free(depth);
+  free(prim);
+  return rc;
 }
