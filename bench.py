@@ -16,8 +16,8 @@ Prints ONE JSON line on rank 0 with `roofline` (fragment kernel vs the HBM-read 
 the host cores over a bounded sample of the same poses).
 """
 import argparse
+import importlib
 import json
-import math
 import os
 import sys
 import time
@@ -30,32 +30,6 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALG_READ_BYTES_PER_PIXEL = 6   # 4 B visibility record + 2 B atlas texel
-
-
-def xorshift32(state):
-    state ^= (state << 13) & 0xFFFFFFFF
-    state ^= state >> 17
-    state ^= (state << 5) & 0xFFFFFFFF
-    return state & 0xFFFFFFFF
-
-
-def pose_sweep(rd, built, n, width, height, first=0, seed=0x19931210):
-    """SURVEY 8(d) config-3 pose generator: seeded, deterministic; pose i of the global sweep."""
-    cents = built.floor_centroids()
-    poses = np.zeros(n, rd.POSE)
-    s = seed
-    for _ in range(first * 3):  # skip the draws of earlier poses so shards are disjoint slices of one sweep
-        s = xorshift32(s)
-    for k in range(n):
-        i = first + k
-        s = xorshift32(s)
-        c = cents[s % len(cents)]
-        s = xorshift32(s)
-        yaw = 2.0 * math.pi * (i % 1024) / 1024.0 + s * 2.0 ** -32
-        s = xorshift32(s)
-        pitch = (s * 2.0 ** -32 - 0.5) * 0.6
-        poses[k] = rd.pose_look((c[0], c[1] + 0.41, c[2]), yaw, pitch, width, height, 0.0)
-    return poses
 
 
 def main():
@@ -75,6 +49,7 @@ def main():
     import torch
     import rust_doom_amd as rd
     from util import META_PATH, ensure_wad
+    sharding = importlib.import_module('rust-doom_amd.sharding')
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -97,7 +72,7 @@ def main():
     t_build = time.perf_counter() - t0
     level = rd.DeviceLevel(built)                      # level arrays now resident in HBM
     batch = rd.Batch(level, args.width, args.height, args.poses)
-    poses = pose_sweep(rd, built, args.poses, args.width, args.height, first=rank * args.poses)
+    poses = sharding.pose_sweep(rd, built, args.poses, args.width, args.height, first=rank * args.poses)
     lights = built.lights_at(0.0)
 
     def barrier():
@@ -120,10 +95,7 @@ def main():
         fixups = t['fixup_pixels']
     barrier()
     elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        el = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+    elapsed = sharding.max_over_ranks(elapsed, dist, 'cuda')
 
     if rank == 0:
         px_per_step = args.poses * args.width * args.height
