@@ -168,6 +168,14 @@ rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *batch, uint32_t first, ui
 /* winning primitive id per pixel (global triangle index in draw order, 0xFFFFFFFF = none) */
 rdoom_status rdoom_batch_read_primitive_ids(rdoom_batch *batch, uint32_t first, uint32_t count, uint32_t *host_out);
 
+/* On-device verification of the exact short forms the fragment kernel uses instead of IEEE division
+ * (rust-doom_amd/csrc/hip/fastmath.hpp).  No reference counterpart: it certifies that the kernels evaluate
+ * static.frag:18-28's divisions and mod() to the same bits as the plain operations.
+ * out_counts: [0] 1/x mismatches, [1] 0.9/x mismatches, [2] inputs swept, [3] mod-certificate violations,
+ * [4] mod samples, [5] samples certified, [6] samples where the short form's floor differs (all rejected),
+ * [7] packed-vs-scalar mismatches.  [0], [1], [3], [7] must be 0. */
+rdoom_status rdoom_selftest_fastmath(uint64_t out_counts[8]);
+
 /* ---- loader + builder: the `wad` crate and `game::level` static-geometry builder ----------- */
 /* Archive::open (wad/src/archive.rs:36-60) + TextureDirectory::from_archive (wad/src/tex.rs:53-107) */
 rdoom_status rdoom_wad_open(const char *wad_path, const char *metadata_path, rdoom_wad **out_wad);

@@ -76,7 +76,7 @@ API_SYMBOLS = [
     'rdoom_wad_open', 'rdoom_wad_close', 'rdoom_wad_num_levels', 'rdoom_wad_level_name',
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
     'rdoom_built_counters', 'rdoom_built_lights_at', 'rdoom_built_start', 'rdoom_built_floor_centroids',
-    'rdoom_pose_look']
+    'rdoom_pose_look', 'rdoom_selftest_fastmath']
 
 _lib = None
 
@@ -118,6 +118,15 @@ def device_count():
 
 def set_device(i):
     _check(lib().rdoom_set_device(int(i)))
+
+
+def selftest_fastmath():
+    """rdoom_selftest_fastmath: exhaustive on-device check of the fragment kernel's exact division forms."""
+    out = (ctypes.c_uint64 * 8)()
+    _check(lib().rdoom_selftest_fastmath(out))
+    keys = ('rcp_mismatches', 'div09_mismatches', 'inputs_swept', 'mod_violations', 'mod_samples', 'mod_certified',
+            'mod_floor_differs', 'packed_mismatches')
+    return dict(zip(keys, [int(x) for x in out]))
 
 
 def wad_name(value):

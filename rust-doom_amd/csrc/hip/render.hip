@@ -18,10 +18,12 @@
 #include <vector>
 
 #include "../common.hpp"
+#include "fastmath.hpp"
 
 #pragma clang fp contract(off)
 
 namespace {
+using namespace rdoom_fm;
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int TILE_W = 64, TILE_H = 64;  // one 256-thread workgroup: 4 waves x 32x32 quadrant, 4x4 pixels per lane
@@ -59,14 +61,17 @@ constexpr uint32_t RASTER_MASKED_BORDER = 1u << 29;    // a texel bordering the 
 constexpr uint32_t RASTER_MASKED_INTERIOR = 1u << 30;  // the texture rectangle itself has transparent texels
 constexpr uint32_t RASTER_MASKED_ANY = RASTER_MASKED_BORDER | RASTER_MASKED_INTERIOR;
 constexpr uint32_t SHADE_POW2_X = 1u << 2, SHADE_POW2_Y = 1u << 3;
+// eligible for the fragment kernel's packed path: flat or wall whose tile sizes are each a power of two in
+// [2^-20, 2^20] or an integer in [1, 4096]; SHADE_NP2 = at least one of them is not a power of two
+constexpr uint32_t SHADE_FAST = 1u << 4, SHADE_NP2 = 1u << 5;
 
 struct alignas(16) ShadeRec {  // 64 bytes
   float wp[3];
   float up[3];
   float vp[3];
   float atlas_u, atlas_v, size_x, size_y, light;
-  uint32_t flags;  // kind (2 bits) | SHADE_POW2_X | SHADE_POW2_Y
-  uint32_t prim;
+  uint32_t flags;  // kind (2 bits) | SHADE_POW2_X | SHADE_POW2_Y | SHADE_FAST | log2(atlas width) << 8 | (texel base >> 10) << 16
+  uint32_t tex;    // (atlas width - 1) | (atlas height - 1) << 16
 };
 static_assert(sizeof(ShadeRec) == 64, "ShadeRec layout");
 
@@ -79,9 +84,11 @@ static_assert(sizeof(TriRec) == 144, "TriRec layout");
 struct DeviceLevelView {
   const LevelTri *tris;
   uint32_t ntri;
-  const uint8_t *flat_atlas;
+  // one u16 texel store: the wall atlas (lo = palette index, bit 15 = transparent) followed, at element
+  // flat_base (a multiple of 1024), by the flat atlas promoted to u16 (hi byte 0: never transparent)
+  const uint16_t *texels;
+  uint32_t flat_base;
   uint32_t flat_w, flat_h;
-  const uint16_t *wall_atlas;
   uint32_t wall_w, wall_h;
   const uint16_t *sky_tex;
   uint32_t sky_w, sky_h;
@@ -218,9 +225,17 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
           sr.size_y = tri.size_y;
           sr.light = (float)pc.lights[(tri.packed >> 8) & 0xFFu] / 255.0f;
           const uint32_t bx = __float_as_uint(tri.size_x), by = __float_as_uint(tri.size_y);
-          sr.flags = kind | (((bx & 0x7FFFFFu) == 0u && tri.size_x > 0.0f) ? SHADE_POW2_X : 0u) |
-                     (((by & 0x7FFFFFu) == 0u && tri.size_y > 0.0f) ? SHADE_POW2_Y : 0u);
-          sr.prim = t;
+          const bool p2x = (bx & 0x7FFFFFu) == 0u && tri.size_x > 0.0f, p2y = (by & 0x7FFFFFu) == 0u && tri.size_y > 0.0f;
+          const bool is_flat = kind == RDOOM_KIND_FLAT;
+          const uint32_t aw = is_flat ? lv.flat_w : lv.wall_w, ah = is_flat ? lv.flat_h : lv.wall_h;
+          const uint32_t lw = aw ? 31u - (uint32_t)__clz(aw) : 0u;
+          auto packed_ok = [](float sz, bool p2) {
+            return p2 ? (sz >= 0x1p-20f && sz <= 0x1p20f) : (sz >= 1.0f && sz <= 4096.0f && floorf(sz) == sz);
+          };
+          const bool fast_ok = packed_ok(tri.size_x, p2x) && packed_ok(tri.size_y, p2y) && kind != RDOOM_KIND_SKY;
+          sr.flags = kind | (p2x ? SHADE_POW2_X : 0u) | (p2y ? SHADE_POW2_Y : 0u) | (fast_ok ? SHADE_FAST : 0u) |
+                     ((p2x && p2y) ? 0u : SHADE_NP2) | (lw << 8) | (((is_flat ? lv.flat_base : 0u) >> 10) << 16);
+          sr.tex = kind == RDOOM_KIND_SKY ? 0u : (((aw - 1u) & 0xFFFFu) | (((ah - 1u) & 0xFFFFu) << 16));
         }
       }
     }
@@ -476,10 +491,13 @@ __device__ __forceinline__ TexelAt texel_coords(const ShadeRec &s, float px, flo
   return t;
 }
 
-__device__ __forceinline__ uint32_t load_texel(const DeviceLevelView &lv, uint32_t kind, int ix, int iy) {
-  if (kind == RDOOM_KIND_FLAT)
-    return lv.flat_atlas[(size_t)(iy & (int)(lv.flat_h - 1)) * lv.flat_w + (size_t)(ix & (int)(lv.flat_w - 1))];
-  return lv.wall_atlas[(size_t)(iy & (int)(lv.wall_h - 1)) * lv.wall_w + (size_t)(ix & (int)(lv.wall_w - 1))];
+// F3: REPEAT + NEAREST on a power-of-two atlas; flats and walls live in one u16 store (see DeviceLevelView)
+__device__ __forceinline__ uint32_t texel_offset(uint32_t flags, uint32_t tex, int ix, int iy) {
+  const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
+  return base + ((((uint32_t)iy & hm) << lw) | ((uint32_t)ix & wm));
+}
+__device__ __forceinline__ uint32_t load_texel(const DeviceLevelView &lv, const ShadeRec &s, int ix, int iy) {
+  return lv.texels[texel_offset(s.flags, s.tex, ix, iy)];
 }
 
 // =================================================================================================
@@ -674,7 +692,7 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
                 const bool must_fetch = (flags & RASTER_MASKED_INTERIOR) != 0u || t.ix < (int)sh.atlas_u ||
                                         t.ix >= (int)(sh.atlas_u + sh.size_x) || t.iy < (int)sh.atlas_v ||
                                         t.iy >= (int)(sh.atlas_v + sh.size_y);
-                if (must_fetch) pass = (load_texel(lv, RDOOM_KIND_WALL, t.ix, t.iy) & 0x8000u) == 0u;
+                if (must_fetch) pass = (load_texel(lv, sh, t.ix, t.iy) & 0x8000u) == 0u;
               }
               if (pass) {
                 best_d[k] = d24;
@@ -717,11 +735,26 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
 // =================================================================================================
 // Kernel 3: fragment kernel (F1..F6): visibility record -> atlas texel -> COLORMAP row -> 8-bit
 // palette index.  One lane per 4 horizontally adjacent pixels: one 16-byte visibility load, one
-// 4-byte packed store.  When the four pixels see the same triangle (the common case) its 64-byte
-// shade record is loaded once and the row terms of the three planes are shared.  COLORMAP (8 KiB)
-// is staged in LDS once per workgroup; a workgroup walks FRAG_CHUNK consecutive 1024-pixel slabs.
+// 4-byte packed store; COLORMAP (8 KiB) is staged in LDS once per workgroup, which walks
+// FRAG_CHUNK consecutive 1024-pixel slabs of one pose (all blocks of a pose run on one XCD).
+//
+// Packed path (96 % of the quads of an E1M1 sweep): the four pixels see the same flat/wall triangle
+// with power-of-two tile sizes.  Its 64-byte shade record is loaded once and the four pixels are
+// shaded branch-free in two float2 halves (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 evaluate the
+// same IEEE operations as their scalar forms, lane by lane).  Exactness devices, all verified or proven:
+//   * 1/rw        = rcp, fma, fma       -- equals the correctly rounded quotient for EVERY binary32 rw with
+//   * 0.9/(d+0.9) = rcp, mul, fma, fma     2^-100 <= |x| <= 2^100 (exhaustive sweep on gfx950,
+//                                          tools/fastmath_exhaustive.hip, and the -m gpu self-test)
+//   * mod by a power of two: x / 2^k == x * 2^-k, and y * floor(q) is exact, so fma(-y, f, x) == x - y * f
+//   * COLORMAP row: every operation of F1/F4/F5 is monotone and rw is monotone along the quad, so when the
+//     rows of the two end pixels agree the two middle pixels have that row too
+//   * mod by an integer tile size: floor(t * RN(1/size)) is certified per pixel by a remainder test (see F2)
+// A quad that fails any precondition (mixed triangles, sky, rw outside the verified range, an uncertified
+// mod, a transparent texel) is appended to an LDS list and shaded afterwards
+// by the general per-pixel body, lane per pixel -- same results, one code path for everything unusual.
 // =================================================================================================
 constexpr int FRAG_CHUNK = 16;
+constexpr int FRAG_WLIST = 128;  // per-wave list of unfinished quads: at most 15 carried over + 64 new
 
 __device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const uint8_t *cmap, float px, float py,
                                               int width, int height, float vr0, float vr1) {
@@ -755,7 +788,7 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
   const uint32_t kind = s.flags & 3u;
   if (kind == RDOOM_KIND_SKY) return shade_sky(lv, cmap, px, py, width, height, pc.vr0, pc.vr1);
   const TexelAt t = texel_coords(s, px, row_w, row_u, row_v);
-  const uint32_t texel = load_texel(lv, kind, t.ix, t.iy);
+  const uint32_t texel = load_texel(lv, s, t.ix, t.iy);
   if (kind == RDOOM_KIND_WALL && (texel & 0x8000u)) return 0x100u;
   const float dist_term = fminf(1.0f, 1.0f - 0.9f / (t.dist + 0.9f));
   const float light = s.light * 2.0f - dist_term;
@@ -769,12 +802,14 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t idx, uint32_t m, uint32_t 
 
 __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
-                                                       const uint32_t *__restrict__ vis, uint32_t quads_per_pose,
+                                                       const uint32_t *__restrict__ vis, uint32_t n_poses,
+                                                       uint32_t chunks_per_pose, uint32_t quads_per_pose,
                                                        uint32_t quads_per_row, uint32_t div_m, uint32_t div_sh,
                                                        int width, int height, uint8_t *__restrict__ fb,
                                                        uint32_t *__restrict__ fix_count, uint2 *__restrict__ fix_list,
                                                        uint32_t fix_cap, uint32_t debug_leak_mod) {
   __shared__ uint8_t cmap[32 * 256];
+  __shared__ uint32_t wlist[4][FRAG_WLIST];
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(lv.colormap);
     uint4 *dst = reinterpret_cast<uint4 *>(cmap);
@@ -782,44 +817,152 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
     dst[threadIdx.x + 256] = src[threadIdx.x + 256];
   }
   __syncthreads();
-  const uint32_t pose = blockIdx.y;
-  const PoseConst &pc = poses[pose];
+  // blockIdx -> (pose, chunk): all chunks of a pose on one XCD (b % 8), like the rasteriser
+  const uint32_t g = blockIdx.x >> 3;
+  const uint32_t pose = (g / chunks_per_pose) * 8u + (blockIdx.x & 7u);
+  const uint32_t chunk = g % chunks_per_pose;
+  if (pose >= n_poses) return;
   const TriRec *prec = recs + (size_t)pose * cap;
   const uint4 *pvis = reinterpret_cast<const uint4 *>(vis) + (size_t)pose * quads_per_pose;
   uint32_t *pfb = reinterpret_cast<uint32_t *>(fb) + (size_t)pose * quads_per_pose;
-  for (int it = 0; it < FRAG_CHUNK; it++) {
-    const uint32_t qi = (blockIdx.x * FRAG_CHUNK + (uint32_t)it) * 256u + threadIdx.x;
-    if (qi >= quads_per_pose) break;
-    const uint32_t row = fast_div(qi, div_m, div_sh), qx = qi - row * quads_per_row;
-    const uint4 ids = pvis[qi];
-    const uint32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
-    const float py = (float)row + 0.5f;
-    const float px0 = (float)(qx * 4u) + 0.5f;
-    uint32_t out = 0, cur_id = NONE;
-    ShadeRec cur;
-    float row_w = 0.0f, row_u = 0.0f, row_v = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (id[k] == NONE) continue;
-      if (id[k] != cur_id) {  // neighbouring pixels nearly always share the triangle: one 64-byte load per run
-        cur = prec[id[k]].s;
-        cur_id = id[k];
-        row_w = fmaf(cur.wp[1], py, cur.wp[2]);
-        row_u = fmaf(cur.up[1], py, cur.up[2]);
-        row_v = fmaf(cur.vp[1], py, cur.vp[2]);
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t *mylist = wlist[threadIdx.x >> 6];
+  uint32_t wn = 0;  // wave-uniform: quads waiting in mylist
+  const PoseConst &pc = poses[pose];
+  // general body: 16 listed quads at a time, lane per pixel.  The list is private to the wave (LDS operations of
+  // one wave execute in order), so no workgroup barrier is involved and waves never wait for each other.
+  auto shade_listed = [&](uint32_t first, uint32_t count) {
+    const uint32_t j = lane >> 2, k = lane & 3u;
+    if (j < count) {
+      const uint32_t qi = mylist[first + j];
+      const uint32_t row = fast_div(qi, div_m, div_sh), qx = qi - row * quads_per_row;
+      const uint32_t id = vis[((size_t)pose * quads_per_pose + qi) * 4u + k];
+      uint32_t c = 0;
+      const uint32_t pix = (row * quads_per_row + qx) * 4u + k;
+      if (id != NONE) {
+        const ShadeRec cur = prec[id].s;
+        const float py = (float)row + 0.5f, px = (float)(qx * 4u + k) + 0.5f;
+        c = shade_pixel(lv, cmap, cur, px, py, fmaf(cur.wp[1], py, cur.wp[2]), fmaf(cur.up[1], py, cur.up[2]),
+                        fmaf(cur.vp[1], py, cur.vp[2]), width, height, pc);
+        // debug_leak_mod != 0 (tests only): pretend every n-th pixel leaked, so fixup_kernel's general rule
+        // is exercised on ordinary pixels too -- the output must not change
+        const bool forced = debug_leak_mod != 0u && pix % debug_leak_mod == 0u;
+        if ((c & 0x100u) || forced) {  // rare: alpha leak, queue the pixel for exact re-resolution
+          const uint32_t slot = atomicAdd(fix_count, 1u);
+          if (slot < fix_cap) fix_list[slot] = make_uint2(pose, pix);
+        }
       }
-      const uint32_t c = shade_pixel(lv, cmap, cur, px0 + (float)k, py, row_w, row_u, row_v, width, height, pc);
-      // debug_leak_mod != 0 (tests only): pretend every n-th pixel leaked, so fixup_kernel's general rule
-      // is exercised on ordinary pixels too -- the output must not change
-      const bool forced = debug_leak_mod != 0u && ((row * quads_per_row + qx) * 4u + (uint32_t)k) % debug_leak_mod == 0u;
-      if ((c & 0x100u) || forced) {  // rare: alpha leak, queue the pixel for exact re-resolution
-        const uint32_t slot = atomicAdd(fix_count, 1u);
-        if (slot < fix_cap) fix_list[slot] = make_uint2(pose, (row * quads_per_row + qx) * 4u + (uint32_t)k);
-      }
-      out |= (c & 0xFFu) << (8 * k);
+      uint32_t v = (c & 0xFFu) << (8u * k);
+      v |= __shfl_xor(v, 1);
+      v |= __shfl_xor(v, 2);
+      if (k == 0) pfb[qi] = v;
     }
-    pfb[qi] = out;
+  };
+  for (int it = 0; it < FRAG_CHUNK; it++) {
+    const uint32_t qi = (chunk * FRAG_CHUNK + (uint32_t)it) * 256u + threadIdx.x;
+    if (qi - lane >= quads_per_pose) break;  // wave-uniform: the whole wave is past the end of the frame
+    const bool valid = qi < quads_per_pose;
+    const uint4 ids = valid ? pvis[qi] : make_uint4(NONE, NONE, NONE, NONE);
+    const bool uniform = (ids.x == ids.y) & (ids.y == ids.z) & (ids.z == ids.w);
+    bool done = false;
+    uint32_t out = 0;
+    if (uniform & (ids.x == NONE)) done = true;  // background (or past the end: nothing is stored)
+    if (uniform & (ids.x != NONE) & (debug_leak_mod == 0u)) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[ids.x].s);
+      const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+      const uint32_t flags = r3.z, tex = r3.w;
+      // (all four loads are issued before the flag is examined: one memory latency, not two)
+      asm volatile("" ::"v"(r0.x), "v"(r1.x), "v"(r2.x));
+      if (flags & SHADE_FAST) {
+        const float wa = __uint_as_float(r0.x), wb = __uint_as_float(r0.y), wc = __uint_as_float(r0.z),
+                    ua = __uint_as_float(r0.w), ub = __uint_as_float(r1.x), uc = __uint_as_float(r1.y),
+                    va = __uint_as_float(r1.z), vb = __uint_as_float(r1.w), vc = __uint_as_float(r2.x),
+                    atlas_u = __uint_as_float(r2.y), atlas_v = __uint_as_float(r2.z), size_x = __uint_as_float(r2.w),
+                    size_y = __uint_as_float(r3.x), light = __uint_as_float(r3.y);
+        const uint32_t row = fast_div(qi, div_m, div_sh), qx = qi - row * quads_per_row;
+        const float py = (float)row + 0.5f;
+        const float px0 = (float)(qx * 4u) + 0.5f;
+        const f32x2 pxa = {px0, px0 + 1.0f}, pxb = {px0 + 2.0f, px0 + 3.0f};
+        const float row_w = fmaf(wb, py, wc), row_u = fmaf(ub, py, uc), row_v = fmaf(vb, py, vc);
+        // F1
+        const f32x2 rwa = pk_fma(splat(wa), pxa, splat(row_w)), rwb = pk_fma(splat(wa), pxb, splat(row_w));
+        const float rw_lo = fminf(rwa.x, rwb.y), rw_hi = fmaxf(rwa.x, rwb.y);  // rw is monotone along the quad
+        const bool in_range = (rw_lo >= 0x1p-100f) & (rw_hi <= 0x1p100f);
+        const f32x2 wwa = exact_rcp2(rwa), wwb = exact_rcp2(rwb);
+        const f32x2 tua = pk_fma(splat(ua), pxa, splat(row_u)) * wwa, tub = pk_fma(splat(ua), pxb, splat(row_u)) * wwb;
+        const f32x2 tva = pk_fma(splat(va), pxa, splat(row_v)) * wwa, tvb = pk_fma(splat(va), pxb, splat(row_v)) * wwb;
+        // F2: mod(t, size) = t - size * floor(t / size).  q0 = t * RN(1/size) equals the quotient exactly for a
+        // power-of-two size; for an integer size it is within |t/size| * 2^-23 of it, and the remainder test
+        // below certifies floor(q0) == floor(RN(t / size)) (else the quad goes to the general body).
+        const f32x2 inv_s = exact_rcp2(f32x2{size_x, size_y});
+        f32x2 qa = tua * splat(inv_s.x), qb = tub * splat(inv_s.x);
+        qa = f32x2{floorf(qa.x), floorf(qa.y)};
+        qb = f32x2{floorf(qb.x), floorf(qb.y)};
+        const f32x2 rxa = pk_fma(splat(-size_x), qa, tua), rxb = pk_fma(splat(-size_x), qb, tub);
+        const f32x2 uxa = rxa + splat(atlas_u), uxb = rxb + splat(atlas_u);
+        f32x2 ha = tva * splat(inv_s.y), hb = tvb * splat(inv_s.y);
+        ha = f32x2{floorf(ha.x), floorf(ha.y)};
+        hb = f32x2{floorf(hb.x), floorf(hb.y)};
+        const f32x2 rya = pk_fma(splat(-size_y), ha, tva), ryb = pk_fma(splat(-size_y), hb, tvb);
+        const f32x2 uya = rya + splat(atlas_v), uyb = ryb + splat(atlas_v);
+        bool mod_ok = true;
+        if (__any((flags & SHADE_NP2) != 0u)) {
+          // Certificate (integer size y, t = x): with guard = 2^-20 * max(|x|, y), guard <= r <= y - guard and
+          // |x| < 2^23 imply that no integer lies between x * RN(1/y) and RN(x / y) (both are within
+          // |x/y| * 2^-22 of x/y, i.e. the true remainder is more than |x| * 2^-22 away from 0 and from y),
+          // and that y * floor is exact.  Power-of-two axes always pass.
+          const bool p2x = (flags & SHADE_POW2_X) != 0u, p2y = (flags & SHADE_POW2_Y) != 0u;
+          mod_ok = mod_cert(tua.x, rxa.x, size_x, p2x) & mod_cert(tua.y, rxa.y, size_x, p2x) & mod_cert(tub.x, rxb.x, size_x, p2x) &
+                   mod_cert(tub.y, rxb.y, size_x, p2x) & mod_cert(tva.x, rya.x, size_y, p2y) & mod_cert(tva.y, rya.y, size_y, p2y) &
+                   mod_cert(tvb.x, ryb.x, size_y, p2y) & mod_cert(tvb.y, ryb.y, size_y, p2y);
+        }
+        // F3
+        const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
+        const uint32_t base2 = base * 2u;  // byte offsets < 2^27: one 32-bit VGPR offset from the uniform base pointer
+        const char *tb = reinterpret_cast<const char *>(lv.texels);
+        const uint32_t o0 = (((uint32_t)cvt_floor_i32(uya.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxa.x) & wm);
+        const uint32_t o1 = (((uint32_t)cvt_floor_i32(uya.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxa.y) & wm);
+        const uint32_t o2 = (((uint32_t)cvt_floor_i32(uyb.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxb.x) & wm);
+        const uint32_t o3 = (((uint32_t)cvt_floor_i32(uyb.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxb.y) & wm);
+        const uint32_t t0 = *reinterpret_cast<const uint16_t *>(tb + (o0 * 2u + base2)),
+                       t1 = *reinterpret_cast<const uint16_t *>(tb + (o1 * 2u + base2)),
+                       t2 = *reinterpret_cast<const uint16_t *>(tb + (o2 * 2u + base2)),
+                       t3 = *reinterpret_cast<const uint16_t *>(tb + (o3 * 2u + base2));
+        // F4, F5 at the two end pixels; the middle pixels only when the ends disagree
+        auto rows_of = [&](f32x2 dist) {
+          const f32x2 dterm = splat(1.0f) - exact_div09_2(dist + splat(0.9f));
+          const f32x2 lgt = splat(light * 2.0f) - f32x2{fminf(1.0f, dterm.x), fminf(1.0f, dterm.y)};
+          const f32x2 tt = (splat(1.0f) - lgt) * splat(32.0f);
+          return f32x2{fminf(fmaxf(floorf(tt.x), 0.0f), 31.0f), fminf(fmaxf(floorf(tt.y), 0.0f), 31.0f)};
+        };
+        const f32x2 rf_ends = rows_of(f32x2{wwa.x, wwb.y});
+        f32x2 rf_mid = splat(rf_ends.x);
+        if (rf_ends.x != rf_ends.y) rf_mid = rows_of(f32x2{wwa.y, wwb.x});
+        const bool opaque = ((t0 | t1 | t2 | t3) & 0x8000u) == 0u;
+        if (in_range & mod_ok & opaque) {
+          const uint32_t c0 = cmap[((uint32_t)(int)rf_ends.x << 8) | (t0 & 0xFFu)],
+                         c1 = cmap[((uint32_t)(int)rf_mid.x << 8) | (t1 & 0xFFu)],
+                         c2 = cmap[((uint32_t)(int)rf_mid.y << 8) | (t2 & 0xFFu)],
+                         c3 = cmap[((uint32_t)(int)rf_ends.y << 8) | (t3 & 0xFFu)];
+          out = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+          done = true;
+        }
+      }
+    }
+    if (done & valid) pfb[qi] = out;
+    const unsigned long long sm = __ballot(!done);
+    if (sm) {  // ordered append of this wave's unfinished quads, then shade full groups of 16
+      if (!done) mylist[wn + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = qi;
+      wn += (uint32_t)__popcll(sm);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      while (wn >= 16u) {
+        wn -= 16u;
+        shade_listed(wn, 16u);
+      }
+    }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (wn) shade_listed(0u, wn);
 }
 
 // =================================================================================================
@@ -886,7 +1029,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
           const ShadeRec sh = prec[rec].s;
           const TexelAt t = texel_coords(sh, px, fmaf(sh.wp[1], py, sh.wp[2]), fmaf(sh.up[1], py, sh.up[2]),
                                          fmaf(sh.vp[1], py, sh.vp[2]));
-          pass = (load_texel(lv, RDOOM_KIND_WALL, t.ix, t.iy) & 0x8000u) == 0u;
+          pass = (load_texel(lv, sh, t.ix, t.iy) & 0x8000u) == 0u;
         }
         if (pass) {
           const uint32_t d24 = __float2uint_rz(fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f));
@@ -988,6 +1131,8 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
     return rdoom::fail(RDOOM_BAD_ARG, "flat atlas %ux%u is not a power of two", d->flat_w, d->flat_h);
   if ((d->wall_w | d->wall_h) && !(is_pow2(d->wall_w) && is_pow2(d->wall_h)))
     return rdoom::fail(RDOOM_BAD_ARG, "wall atlas %ux%u is not a power of two", d->wall_w, d->wall_h);
+  if (d->flat_w > 32768 || d->flat_h > 32768 || d->wall_w > 32768 || d->wall_h > 32768)
+    return rdoom::fail(RDOOM_BAD_ARG, "atlas larger than 32768 texels on a side");
   // flatten the draws into one primitive list in draw order (primitive id == position)
   std::vector<LevelTri> tris;
   // Alpha-test classification of a wall texture (all its animation frames): bit 0 = a texel in the
@@ -1085,8 +1230,18 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
   };
   hipError_t e = upload(&lv->d_tris, tris.data(), tris.size() * sizeof(LevelTri));
-  if (e == hipSuccess) e = upload(&lv->d_flat, d->flat_atlas, (size_t)d->flat_w * d->flat_h);
-  if (e == hipSuccess) e = upload(&lv->d_wall, d->wall_atlas, (size_t)d->wall_w * d->wall_h * 2);
+  // unified u16 texel store: wall atlas, then (at a multiple of 1024 elements) the flat atlas promoted to u16
+  const size_t wall_n = d->wall_atlas ? (size_t)d->wall_w * d->wall_h : 0;
+  const size_t flat_n = d->flat_atlas ? (size_t)d->flat_w * d->flat_h : 0;
+  const size_t flat_base = (wall_n + 1023) / 1024 * 1024;
+  if (flat_base + flat_n >= ((size_t)1 << 26)) {
+    rdoom_level_destroy(lv);
+    return rdoom::fail(RDOOM_BAD_LEVEL, "atlases too large (%zu texels)", flat_base + flat_n);
+  }
+  std::vector<uint16_t> texels(flat_base + flat_n + 1, 0);  // never empty: masked-off lanes read element 0
+  if (wall_n) std::memcpy(texels.data(), d->wall_atlas, wall_n * 2);
+  for (size_t i = 0; i < flat_n; i++) texels[flat_base + i] = d->flat_atlas[i];
+  if (e == hipSuccess) e = upload(&lv->d_wall, texels.data(), texels.size() * 2);
   if (e == hipSuccess) e = upload(&lv->d_sky, d->sky_texture, (size_t)d->sky_w * d->sky_h * 2);
   if (e == hipSuccess) e = upload(&lv->d_cmap, d->colormap, 32 * 256);
   if (e != hipSuccess) {
@@ -1096,10 +1251,10 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
   }
   lv->view.tris = (const LevelTri *)lv->d_tris;
   lv->view.ntri = lv->ntri;
-  lv->view.flat_atlas = (const uint8_t *)lv->d_flat;
+  lv->view.texels = (const uint16_t *)lv->d_wall;
+  lv->view.flat_base = (uint32_t)flat_base;
   lv->view.flat_w = d->flat_w;
   lv->view.flat_h = d->flat_h;
-  lv->view.wall_atlas = (const uint16_t *)lv->d_wall;
   lv->view.wall_w = d->wall_w;
   lv->view.wall_h = d->wall_h;
   lv->view.sky_tex = (const uint16_t *)lv->d_sky;
@@ -1246,9 +1401,11 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   const uint32_t fblocks = (qpp + FRAG_CHUNK * 256 - 1) / (FRAG_CHUNK * 256);
   static const uint32_t debug_leak_mod = getenv("RDOOM_DEBUG_LEAK_MOD") ? (uint32_t)atoi(getenv("RDOOM_DEBUG_LEAK_MOD")) : 0u;
   HIP_TRY(hipMemsetAsync(b->d_fix_count, 0, 2 * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(fragment_kernel, dim3(fblocks, n), dim3(256), 0, st, lv->view, b->d_recs, b->cap, b->d_poses,
-                     b->d_vis, qpp, qpr, div_m, div_sh, W, H, b->d_fb, b->d_fix_count, b->d_fix_list, b->fix_cap,
-                     debug_leak_mod);
+  const uint64_t fgrid = (uint64_t)((n + 7) / 8) * 8ull * fblocks;
+  if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
+  hipLaunchKernelGGL(fragment_kernel, dim3((uint32_t)fgrid), dim3(256), 0, st, lv->view, b->d_recs, b->cap, b->d_poses,
+                     b->d_vis, n, fblocks, qpp, qpr, div_m, div_sh, W, H, b->d_fb, b->d_fix_count, b->d_fix_list,
+                     b->fix_cap, debug_leak_mod);
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap,
                      b->d_poses, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow,
                      b->d_fix_count, b->d_fix_list, b->fix_cap, b->d_vis, b->want_prim ? b->d_prim : nullptr, b->d_fb,

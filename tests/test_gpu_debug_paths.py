@@ -1,0 +1,40 @@
+"""GPU: the rarely taken paths, forced through environment switches the library reads once per process
+(hence child processes):
+  RDOOM_DEBUG_LEAK_MOD=n  every n-th pixel is treated as an alpha leak, so fixup_kernel's general per-pixel
+                          rule (all candidates of the tile, lexicographic (depth, primitive) minimum) re-resolves
+                          ordinary pixels -- output must be unchanged;
+  RDOOM_NO_BINS=1         the rasteriser's fallback scan (no per-tile bins), as used when a pose overflows them."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_child(env_extra, args=('0', '320', '200', '6')):
+    env = dict(os.environ, **env_extra)
+    p = subprocess.run([sys.executable, os.path.join(HERE, 'gpu_child_case.py'), *args], env=env, cwd=HERE,
+                       capture_output=True, text=True, timeout=600)
+    m = re.search(r'RESULT bad=(\d+) fixups=(\d+)', p.stdout)
+    assert m, p.stdout + p.stderr
+    return int(m.group(1)), int(m.group(2))
+
+
+def test_forced_alpha_leak_fixups_do_not_change_the_image():
+    bad, fixups = run_child({'RDOOM_DEBUG_LEAK_MOD': '97'})
+    assert bad == 0
+    assert fixups > 3000  # about 1/97 of 6 x 320 x 200 covered pixels went through fixup_kernel
+
+
+def test_fallback_scan_without_bins():
+    bad, _ = run_child({'RDOOM_NO_BINS': '1'})
+    assert bad == 0
+
+
+def test_child_case_plain():
+    bad, fixups = run_child({})
+    assert bad == 0 and fixups < 1000
