@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,7 +28,7 @@ using namespace rdoom_fm;
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int TILE_W = 64, TILE_H = 64;  // one 256-thread workgroup: 4 waves x 32x32 quadrant, 4x4 pixels per lane
-constexpr int QCAP = 256;
+constexpr int QCAP = 64;
 
 // ---- level-constant triangle record (built once per level on the host) -----------------------
 struct alignas(16) LevelTri {  // 96 bytes
@@ -55,7 +56,7 @@ struct alignas(16) RasterRec {  // 80 bytes
   uint32_t flags;               // prim id (24 bits) | tl << 24 | kind << 27 | RASTER_MASKED_*
   uint32_t pad[2];
 };
-static_assert(sizeof(RasterRec) == 80, "RasterRec layout");
+static_assert(sizeof(RasterRec) == 80 && offsetof(RasterRec, zp) == 36 && offsetof(RasterRec, bb0) == 60, "RasterRec layout");
 
 constexpr uint32_t RASTER_MASKED_BORDER = 1u << 29;    // a texel bordering the texture rectangle is transparent
 constexpr uint32_t RASTER_MASKED_INTERIOR = 1u << 30;  // the texture rectangle itself has transparent texels
@@ -252,8 +253,9 @@ __device__ __forceinline__ uint32_t depth_bucket(float wmin) {
 
 __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
                                                     int width, int height, uint32_t kinds_mask,
-                                                    TriRec *__restrict__ recs, uint4 *__restrict__ sorted,
-                                                    uint32_t *__restrict__ counts, uint32_t cap) {
+                                                    TriRec *__restrict__ recs, TriRec *__restrict__ tmp_recs,
+                                                    uint4 *__restrict__ sorted, uint32_t *__restrict__ counts,
+                                                    uint32_t cap) {
   __shared__ uint32_t hist[SORT_BUCKETS];
   __shared__ uint16_t keys[SORT_KEY_CAP];
   __shared__ uint32_t wcnt[4];
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
   const PoseConst &pc = poses[pose];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   TriRec *prec = recs + (size_t)pose * cap;
+  TriRec *ptmp = tmp_recs + (size_t)pose * cap;  // records in compaction (= primitive) order, before the sort
   uint4 *psorted = sorted + (size_t)pose * cap;
   for (uint32_t i = tid; i < SORT_BUCKETS; i += 256) hist[i] = 0;
   __syncthreads();
@@ -283,44 +286,53 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
       total += c;
     }
     if (ok) {
-      prec[off].r = rr;
-      prec[off].s = sr;
+      ptmp[off].r = rr;
+      ptmp[off].s = sr;
       const uint32_t bucket = depth_bucket(wkey);
       if (off < SORT_KEY_CAP) {
         keys[off] = (uint16_t)bucket;
         atomicAdd(&hist[bucket], 1u);
       }
-      psorted[off] = make_uint4(rr.bb0, rr.bb1, off, bucket);  // identity order; overwritten by the sort below
     }
     n += total;
     __syncthreads();
   }
   if (tid == 0) counts[pose] = n;
-  if (n > SORT_KEY_CAP) return;  // too many for the LDS key array: leave primitive order (still correct)
-  // exclusive scan of the histogram: 8 buckets per thread + a 256-wide block scan
-  uint32_t local[8], sum = 0;
+  const bool sortable = n <= SORT_KEY_CAP;  // else too many for the LDS key array: primitive order (still correct)
+  if (sortable) {
+    // exclusive scan of the histogram: 8 buckets per thread + a 256-wide block scan
+    uint32_t local[8], sum = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    local[k] = sum;
-    sum += hist[tid * 8 + k];
-  }
-  scan_tmp[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
+    for (int k = 0; k < 8; k++) {
+      local[k] = sum;
+      sum += hist[tid * 8 + k];
+    }
+    scan_tmp[tid] = sum;
     __syncthreads();
-    scan_tmp[tid] += v;
-    __syncthreads();
-  }
-  const uint32_t before = scan_tmp[tid] - sum;
+    for (int d = 1; d < 256; d <<= 1) {
+      const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
+      __syncthreads();
+      scan_tmp[tid] += v;
+      __syncthreads();
+    }
+    const uint32_t before = scan_tmp[tid] - sum;
 #pragma unroll
-  for (int k = 0; k < 8; k++) hist[tid * 8 + k] = before + local[k];
-  __syncthreads();
+    for (int k = 0; k < 8; k++) hist[tid * 8 + k] = before + local[k];
+    __syncthreads();
+  }
+  // move every record to its near-to-far position: record index == position in the sorted list from here on
+  // (bin/raster/fragment gather records by that index; ptmp was written by this workgroup, same CU, after a barrier)
   for (uint32_t i = tid; i < n; i += 256) {
-    const uint32_t bucket = keys[i];
-    const uint32_t pos = atomicAdd(&hist[bucket], 1u);
-    const RasterRec &r = prec[i].r;  // written above by this workgroup (same CU: L1/L2 coherent after the barrier)
-    psorted[pos] = make_uint4(r.bb0, r.bb1, i, bucket);
+    const uint32_t bucket = sortable ? (uint32_t)keys[i] : 0u;
+    const uint32_t pos = sortable ? atomicAdd(&hist[bucket], 1u) : i;
+    const uint4 *src = reinterpret_cast<const uint4 *>(&ptmp[i]);
+    uint4 *dst = reinterpret_cast<uint4 *>(&prec[pos]);
+    uint4 v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = src[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) dst[k] = v[k];
+    psorted[pos] = make_uint4(v[3].w, v[4].x, pos, bucket);  // RasterRec::bb0, bb1 (dwords 15, 16)
   }
 }
 
@@ -350,13 +362,14 @@ __device__ __forceinline__ uint32_t tile_quadrant_mask(const uint4 c0, const uin
   return qm;
 }
 
-// Same corner argument for the whole 64x64 tile: false = no pixel of the tile can be covered.
-__device__ __forceinline__ bool tile_may_touch(const uint4 c0, const uint4 c1, const uint4 c2, int tx0, int ty0) {
+// Same corner argument for any rectangle of pixel centres [xl, xh] x [yl, yh]: false = no pixel in it can be
+// covered.  Monotonicity makes it hierarchical: a rectangle that fails rules out every rectangle inside it.
+__device__ __forceinline__ bool rect_may_touch(const uint4 c0, const uint4 c1, const uint4 c2, float xl, float xh,
+                                               float yl, float yh) {
   const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
               e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
               e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x),
               za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
-  const float xl = (float)tx0 + 0.5f, xh = (float)tx0 + 63.5f, yl = (float)ty0 + 0.5f, yh = (float)ty0 + 63.5f;
   const float m0 = fmaf(e0a, e0a > 0.0f ? xh : xl, fmaf(e0b, e0b > 0.0f ? yh : yl, e0c));
   const float m1 = fmaf(e1a, e1a > 0.0f ? xh : xl, fmaf(e1b, e1b > 0.0f ? yh : yl, e1c));
   const float m2 = fmaf(e2a, e2a > 0.0f ? xh : xl, fmaf(e2b, e2b > 0.0f ? yh : yl, e2c));
@@ -364,98 +377,148 @@ __device__ __forceinline__ bool tile_may_touch(const uint4 c0, const uint4 c1, c
   const float zf = fmaf(za, za > 0.0f ? xh : xl, fmaf(zb, zb > 0.0f ? yh : yl, zc));
   return (m0 >= 0.0f) & (m1 >= 0.0f) & (m2 >= 0.0f) & (zn <= 1.0f) & (zf >= 0.0f);
 }
+__device__ __forceinline__ bool tile_may_touch(const uint4 c0, const uint4 c1, const uint4 c2, int tx0, int ty0) {
+  return rect_may_touch(c0, c1, c2, (float)tx0 + 0.5f, (float)tx0 + 63.5f, (float)ty0 + 0.5f, (float)ty0 + 63.5f);
+}
 
 // =================================================================================================
-// Kernel 1b: binning.  One workgroup per pose turns the near-to-far triangle list into per-tile
-// lists: each wave takes a triangle, its 64 lanes take 64 tiles of the bbox's tile rectangle and run
-// the exact quadrant test; count -> scan -> fill.  The rasteriser then starts from a short list
-// (a handful of entries per tile) instead of scanning every visible triangle of the pose.
-// entry = record index | quadrant mask << 28.  If a pose needs more than entry_cap entries (or the
-// frame has more than MAX_TILES tiles) its overflow flag is set and the rasteriser scans instead.
+// Kernel 1b: binning.  One 512-thread workgroup per pose turns the near-to-far record list into
+// per-tile lists: count -> scan -> fill.  The unit of work is a (triangle, tile of its bbox) pair: the
+// raster coefficients of BIN_CHUNK triangles are staged in LDS together with an exclusive prefix sum of
+// their bbox tile counts, and every lane finds its pair by binary search in that prefix -- lanes stay busy
+// whatever the mix of one-tile and whole-frame triangles, and the exact tile/quadrant test runs from LDS.
+// entry = record index | quadrant mask << 28.  Pairs are visited in list order 512 at a time, so a tile's
+// list is near-to-far up to that window; the rasteriser re-sorts each list chunk by record index (= depth
+// rank).  Order only affects early-z efficiency: the winner is order-independent.  If a pose needs more than
+// entry_cap entries (or the frame has more than MAX_TILES tiles) its overflow flag is set and the
+// rasteriser scans the sorted list instead.
 // =================================================================================================
 constexpr uint32_t MAX_TILES = 8192;
+constexpr int BIN_THREADS = 512;
+constexpr uint32_t BIN_CHUNK = 512;  // triangles staged per round: one per thread
 
-constexpr int BIN_THREADS = 1024;
-
-__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restrict__ recs, const uint4 *__restrict__ sorted,
-                                                  const uint32_t *__restrict__ counts, uint32_t cap, int tiles_x,
-                                                  int tiles_y, uint2 *__restrict__ tile_hdr,
-                                                  uint32_t *__restrict__ entries, uint32_t entry_cap,
-                                                  uint32_t *__restrict__ overflow) {
-  __shared__ uint32_t tile_cnt[MAX_TILES];
-  __shared__ uint32_t tile_off[MAX_TILES];
-  __shared__ uint32_t scan_tmp[256];
+__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restrict__ recs,
+                                                          const uint4 *__restrict__ sorted,
+                                                          const uint32_t *__restrict__ counts, uint32_t cap,
+                                                          int tiles_x, int tiles_y, uint2 *__restrict__ tile_hdr,
+                                                          uint32_t *__restrict__ entries, uint32_t entry_cap,
+                                                          uint32_t *__restrict__ overflow) {
+  extern __shared__ uint32_t bin_dyn[];  // tile_cnt[T], tile_off[T]
+  __shared__ uint4 coef[BIN_CHUNK][3];   // e[9], zp[3] of the staged triangles
+  __shared__ uint2 bbox[BIN_CHUNK];
+  __shared__ uint32_t trange[BIN_CHUNK];  // tile rectangle to visit: tx0 | ty0 << 8 | width << 16
+  __shared__ uint32_t pref[BIN_CHUNK + 1];
+  __shared__ uint32_t scan_tmp[BIN_THREADS];
   const uint32_t pose = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  constexpr uint32_t NW = BIN_THREADS / 64;
+  const int tid = threadIdx.x;
   const uint32_t T = (uint32_t)(tiles_x * tiles_y);
   if (T > MAX_TILES) {
     if (tid == 0) overflow[pose] = 1u;
     return;
   }
+  uint32_t *tile_cnt = bin_dyn, *tile_off = bin_dyn + T;
   const TriRec *prec = recs + (size_t)pose * cap;
   const uint4 *psorted = sorted + (size_t)pose * cap;
   uint2 *hdr = tile_hdr + (size_t)pose * T;
   uint32_t *pent = entries + (size_t)pose * entry_cap;
   const uint32_t n = counts[pose];
   for (uint32_t i = tid; i < T; i += BIN_THREADS) tile_cnt[i] = 0;
-  __syncthreads();
   for (int pass = 0; pass < 2; pass++) {
-    for (uint32_t si = (uint32_t)wave; si < n; si += NW) {
-      const uint4 ent = psorted[si];  // wave-uniform
-      const int x0 = (int)(ent.x & 0xFFFFu), y0 = (int)(ent.x >> 16), x1 = (int)(ent.y & 0xFFFFu),
-                y1 = (int)(ent.y >> 16);
-      const int tx0 = x0 >> 6, ty0 = y0 >> 6, ntx = (x1 >> 6) - tx0 + 1, nt = ntx * ((y1 >> 6) - ty0 + 1);
-      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[ent.z]);
-      const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2];
-      const float inv_ntx = 1.0f / (float)ntx;
-      for (int tb = 0; tb < nt; tb += 64) {
-        const int t = tb + lane;
-        if (t < nt) {
-          const int ty = (int)(((float)t + 0.5f) * inv_ntx), tx = t - ty * ntx;  // t / ntx (t < 8192: exact)
-          uint32_t qm = 0;
-          if (tile_may_touch(c0, c1, c2, (tx0 + tx) * 64, (ty0 + ty) * 64))
-            qm = tile_quadrant_mask(c0, c1, c2, x0, y0, x1, y1, (tx0 + tx) * 64, (ty0 + ty) * 64);
-          if (qm) {
-            const uint32_t tile = (uint32_t)((ty0 + ty) * tiles_x + tx0 + tx);
-            if (pass == 0) {
-              atomicAdd(&tile_cnt[tile], 1u);
-            } else {
-              const uint32_t pos = atomicAdd(&tile_off[tile], 1u);
-              if (pos < entry_cap) pent[pos] = ent.z | (qm << 28);
-            }
+    for (uint32_t cbase = 0; cbase < n; cbase += BIN_CHUNK) {
+      const uint32_t cn = min(BIN_CHUNK, n - cbase);
+      __syncthreads();  // previous round's readers of coef/pref are done (and tile_cnt / tile_off are ready)
+      uint32_t nt = 0;
+      if ((uint32_t)tid < cn) {
+        const uint4 ent = psorted[cbase + tid];  // (bb0, bb1, record index == cbase + tid, depth bucket)
+        const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[cbase + tid]);
+        const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2];
+        coef[tid][0] = c0;
+        coef[tid][1] = c1;
+        coef[tid][2] = c2;
+        bbox[tid] = make_uint2(ent.x, ent.y);
+        int tx0 = (int)((ent.x & 0xFFFFu) >> 6), ty0 = (int)((ent.x >> 16) >> 6), tx1 = (int)((ent.y & 0xFFFFu) >> 6),
+            ty1 = (int)((ent.y >> 16) >> 6);
+        if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 32) {
+          // a big tile rectangle (typically a triangle that crosses the eye plane: bbox = whole frame, S6): shrink
+          // it to the tile rows / columns whose full-width / full-height strip can be touched at all.  Exact
+          // (rect_may_touch is conservative and hierarchical), so no tile that passes the per-tile test is lost.
+          const float fx0 = (float)(tx0 * 64) + 0.5f, fx1 = (float)(tx1 * 64) + 63.5f;
+          const float fy0 = (float)(ty0 * 64) + 0.5f, fy1 = (float)(ty1 * 64) + 63.5f;
+          while (ty0 <= ty1 && !rect_may_touch(c0, c1, c2, fx0, fx1, (float)(ty0 * 64) + 0.5f, (float)(ty0 * 64) + 63.5f)) ty0++;
+          while (ty1 >= ty0 && !rect_may_touch(c0, c1, c2, fx0, fx1, (float)(ty1 * 64) + 0.5f, (float)(ty1 * 64) + 63.5f)) ty1--;
+          while (tx0 <= tx1 && !rect_may_touch(c0, c1, c2, (float)(tx0 * 64) + 0.5f, (float)(tx0 * 64) + 63.5f, fy0, fy1)) tx0++;
+          while (tx1 >= tx0 && !rect_may_touch(c0, c1, c2, (float)(tx1 * 64) + 0.5f, (float)(tx1 * 64) + 63.5f, fy0, fy1)) tx1--;
+        }
+        nt = (tx1 >= tx0 && ty1 >= ty0) ? (uint32_t)((tx1 - tx0 + 1) * (ty1 - ty0 + 1)) : 0u;
+        trange[tid] = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)(tx1 - tx0 + 1) << 16);  // tiles per side <= 128
+      }
+      scan_tmp[tid] = nt;
+      __syncthreads();
+      for (int d = 1; d < BIN_THREADS; d <<= 1) {
+        const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
+        __syncthreads();
+        scan_tmp[tid] += v;
+        __syncthreads();
+      }
+      pref[tid] = scan_tmp[tid] - nt;  // exclusive; entries past cn repeat the total
+      const uint32_t W = scan_tmp[BIN_THREADS - 1];
+      if (tid == 0) pref[BIN_CHUNK] = W;
+      __syncthreads();
+      for (uint32_t w = (uint32_t)tid; w < W; w += BIN_THREADS) {
+        // largest i with pref[i] <= w (pref non-decreasing, pref[0] = 0, pref[BIN_CHUNK] = W > w); triangles
+        // past cn have pref == W and are never selected
+        uint32_t lo = 0, hi = BIN_CHUNK;
+#pragma unroll
+        for (int step = 0; step < 9; step++) {  // log2(BIN_CHUNK)
+          const uint32_t mid = (lo + hi) >> 1;
+          const bool le = pref[mid] <= w;
+          lo = le ? mid : lo;
+          hi = le ? hi : mid;
+        }
+        const uint32_t t = w - pref[lo];
+        const uint2 bb = bbox[lo];
+        const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
+        const uint32_t tr = trange[lo];
+        const int tx0 = (int)(tr & 0xFFu), ty0 = (int)((tr >> 8) & 0xFFu), ntx = (int)(tr >> 16);
+        const int ty = (int)(((float)t + 0.5f) / (float)ntx), tx = (int)t - ty * ntx;  // t / ntx (t < 8192: exact)
+        const uint4 c0 = coef[lo][0], c1 = coef[lo][1], c2 = coef[lo][2];
+        uint32_t qm = 0;
+        if (tile_may_touch(c0, c1, c2, (tx0 + tx) * 64, (ty0 + ty) * 64))
+          qm = tile_quadrant_mask(c0, c1, c2, x0, y0, x1, y1, (tx0 + tx) * 64, (ty0 + ty) * 64);
+        if (qm) {
+          const uint32_t tile = (uint32_t)((ty0 + ty) * tiles_x + tx0 + tx);
+          if (pass == 0) {
+            atomicAdd(&tile_cnt[tile], 1u);
+          } else {
+            const uint32_t pos = atomicAdd(&tile_off[tile], 1u);
+            if (pos < entry_cap) pent[pos] = (cbase + lo) | (qm << 28);
           }
         }
       }
     }
     __syncthreads();
     if (pass == 1) break;
-    // exclusive scan of tile_cnt -> tile_off (first 256 threads own T/256 consecutive tiles each); headers out
-    const uint32_t per = (T + 255u) / 256u, lo = min((uint32_t)tid * per, T), hi = min(lo + per, T);
+    // exclusive scan of tile_cnt -> tile_off (thread t owns T/512 consecutive tiles); headers out
+    const uint32_t per = (T + BIN_THREADS - 1u) / BIN_THREADS, lo = min((uint32_t)tid * per, T), hi = min(lo + per, T);
     uint32_t sum = 0;
-    if (tid < 256) {
-      for (uint32_t i = lo; i < hi; i++) sum += tile_cnt[i];
-      scan_tmp[tid] = sum;
-    }
+    for (uint32_t i = lo; i < hi; i++) sum += tile_cnt[i];
+    scan_tmp[tid] = sum;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-      const uint32_t v = (tid < 256 && tid >= d) ? scan_tmp[tid - d] : 0u;
+    for (int d = 1; d < BIN_THREADS; d <<= 1) {
+      const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
       __syncthreads();
-      if (tid < 256) scan_tmp[tid] += v;
+      scan_tmp[tid] += v;
       __syncthreads();
     }
-    const uint32_t total = scan_tmp[255];
-    if (tid < 256) {
-      uint32_t run = scan_tmp[tid] - sum;
-      for (uint32_t i = lo; i < hi; i++) {
-        tile_off[i] = run;
-        hdr[i] = make_uint2(run, tile_cnt[i]);
-        run += tile_cnt[i];
-      }
+    const uint32_t total = scan_tmp[BIN_THREADS - 1];
+    uint32_t run = scan_tmp[tid] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+      tile_off[i] = run;
+      hdr[i] = make_uint2(run, tile_cnt[i]);
+      run += tile_cnt[i];
     }
     if (tid == 0) overflow[pose] = total > entry_cap ? 1u : 0u;
-    __syncthreads();
-    if (total > entry_cap) return;
+    if (total > entry_cap) return;  // uniform
   }
 }
 
@@ -515,7 +578,7 @@ __device__ __forceinline__ uint32_t load_texel(const DeviceLevelView &lv, const 
 // XCD's L2.
 // =================================================================================================
 template <bool STATS>
-__global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+__global__ __launch_bounds__(256, 5) void raster_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                      const uint4 *__restrict__ sorted,
                                                      const uint32_t *__restrict__ counts, uint32_t cap,
                                                      uint32_t n_poses, int width, int height, int tiles_x,
@@ -527,9 +590,10 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
   // STATS (debug builds of the launch only): [0] queue entries seen by waves, [1] past the quadrant bbox,
   // [2] past the lane-level rejection (__any(need)), [3] lanes needing, [4] fast bodies, [5] lanes in fast
   // bodies, [6] general bodies, [7] lanes in general bodies, [8] coarse tests, [9] coarse hits
-  unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __shared__ TriRec q[QCAP];
   __shared__ uint32_t qidx[QCAP];
+  __shared__ uint32_t qraw[QCAP];
   __shared__ uint32_t wcnt[4];
   const uint32_t b = blockIdx.x;
   const uint32_t T = (uint32_t)(tiles_x * tiles_y);
@@ -555,18 +619,30 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
   const uint2 hdr = binned ? tile_hdr[(size_t)pose * T + tile] : make_uint2(0u, counts[pose]);
   const uint32_t *pent = entries + (size_t)pose * entry_cap + hdr.x;
   const uint32_t count = hdr.y;
-  for (uint32_t base = 0; base < count; base += 256u) {
+  for (uint32_t base = 0; base < count; base += (uint32_t)QCAP) {
     uint32_t n;
     if (binned) {
-      n = min(256u, count - base);
-      if ((uint32_t)tid < n) qidx[tid] = pent[base + (uint32_t)tid];
+      // the tile's list is near-to-far only up to the binning kernel's 512-pair window: rank-sort this chunk by
+      // record index (= depth rank) so early-z sees the nearest triangles first
+      n = min((uint32_t)QCAP, count - base);
+      uint32_t mine = 0;
+      if ((uint32_t)tid < n) {
+        mine = pent[base + (uint32_t)tid];
+        qraw[tid] = mine;
+      }
+      __syncthreads();
+      if ((uint32_t)tid < n) {
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) rank += ((qraw[j] & 0x0FFFFFFFu) < (mine & 0x0FFFFFFFu)) ? 1u : 0u;
+        qidx[rank] = mine;  // record indices within a tile list are distinct
+      }
       __syncthreads();
     } else {
     // ---- fallback coarse scan (pose without complete bins): one triangle per lane, packed bbox vs tile,
     // exact quadrant test for the survivors, ordered compaction
-    const uint32_t i = base + (uint32_t)tid;
+    const uint32_t i = base + (uint32_t)tid;  // QCAP triangles per round (the queue holds QCAP records)
     uint32_t qm = 0, rec_index = 0;
-    if (i < count) {
+    if (tid < QCAP && i < count) {
       const uint4 bb = psorted[i];  // (bb0, bb1, record index, depth bucket), near to far
       rec_index = bb.z;
       const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
@@ -631,8 +707,16 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
       // (RASTER_MASKED_BORDER) is treated as opaque here; the rare pixel whose float mod lands on the ring
       // is caught by the fragment kernel (it sees a transparent texel) and re-resolved by fixup_kernel.
       const float rwn = fmaf(wa, wa > 0.0f ? pxlo : pxhi, fmaf(wb, wb > 0.0f ? pylo : pyhi, wc));
-      const bool fast = need & (bx >= x0) & (bx + 3 <= x1) & (by >= y0) & (by + 3 <= y1) & (zn >= 0.0f) &
-                        (zf <= 1.0f) & (rwn > 0.0f) & ((flags & RASTER_MASKED_INTERIOR) == 0u);
+      const bool fast = need & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) & ((flags & RASTER_MASKED_INTERIOR) == 0u);
+      // pixels of my block outside the triangle's bbox (S6) never win: bit k of `outside` (k = 4 * row + column).
+      // need guarantees the block overlaps the bbox, so the column and row ranges below are non-empty.
+      uint32_t outside = 0u;
+      if (__any(fast & !((bx >= x0) & (bx + 3 <= x1) & (by >= y0) & (by + 3 <= y1)))) {
+        const int clo = max(x0 - bx, 0), chi = min(x1 - bx, 3), rlo = max(y0 - by, 0), rhi = min(y1 - by, 3);
+        const uint32_t cm = ((2u << chi) - 1u) & ~((1u << clo) - 1u);                // columns inside, 4 bits
+        const uint32_t rows = ((16u << (4 * rhi)) - 1u) & ~((1u << (4 * rlo)) - 1u);  // all pixels of the rows inside
+        outside = ~((cm * 0x1111u) & rows) & 0xFFFFu;
+      }
       bool redo = false, updated = false;
       if (STATS && __any(fast)) st[4]++, st[5] += (unsigned long long)__popcll(__ballot(fast));
       if (fast) {
@@ -647,7 +731,8 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
             const float px = pxlo + (float)rx;
             const float em = fminf(fminf(fmaf(e0a, px, t0), fmaf(e1a, px, t1)), fmaf(e2a, px, t2));
             const uint32_t d24 = __float2uint_rz(fmaf(fmaf(za, px, tz), 16777215.0f, 0.5f));
-            const bool win = (em > 0.0f) & (d24 < best_d[k]);
+            const uint32_t d24m = d24 | (uint32_t)__builtin_amdgcn_sbfe((int)outside, k, 1);  // all ones when outside
+            const bool win = (em > 0.0f) & (d24m < best_d[k]);
             redo |= (em == 0.0f) | ((em > 0.0f) & (d24 == best_d[k]));
             best_d[k] = win ? d24 : best_d[k];
             best_r[k] = win ? ridx : best_r[k];
@@ -656,7 +741,14 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
         }
       }
       if (__any(need & (!fast | redo))) {
-        if (STATS) st[6]++, st[7] += (unsigned long long)__popcll(__ballot(need & (!fast | redo)));
+        if (STATS) {
+          st[6]++, st[7] += (unsigned long long)__popcll(__ballot(need & (!fast | redo)));
+          // why: [10] depth range, [11] 1/w <= 0 in the block, [12] masked texture, [13] tie replay
+          st[10] += (unsigned long long)__popcll(__ballot(need & !((zn >= 0.0f) & (zf <= 1.0f))));
+          st[11] += (unsigned long long)__popcll(__ballot(need & !(rwn > 0.0f)));
+          st[12] += (unsigned long long)__popcll(__ballot(need & ((flags & RASTER_MASKED_INTERIOR) != 0u)));
+          st[13] += (unsigned long long)__popcll(__ballot(need & fast & redo));
+        }
         if (need & (!fast | redo)) {
           const uint32_t prim = flags & 0xFFFFFFu;
 #pragma unroll
@@ -713,7 +805,7 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
     __syncthreads();
   }
   if (STATS && lane == 0)
-    for (int k = 0; k < 10; k++) atomicAdd(&stats[k], st[k]);
+    for (int k = 0; k < 16; k++) atomicAdd(&stats[k], st[k]);
 #pragma unroll
   for (int ry = 0; ry < 4; ry++) {
     const int iy = by + ry;
@@ -1084,7 +1176,8 @@ struct rdoom_batch {
   const rdoom_level *level = nullptr;
   uint32_t width = 0, height = 0, max_poses = 0, cap = 0, last_n = 0;
   PoseConst *d_poses = nullptr;
-  TriRec *d_recs = nullptr;   // max_poses x cap records (setup -> raster, fragment)
+  TriRec *d_recs = nullptr;   // max_poses x cap records in near-to-far order (setup -> bin, raster, fragment)
+  TriRec *d_tmp_recs = nullptr;  // same size: setup's compaction-order staging
   uint4 *d_sorted = nullptr;  // per pose: (bbox, record index, depth bucket) near-to-far (coarse test input)
   uint2 *d_tile_hdr = nullptr;     // per (pose, tile): (first entry, entry count)
   uint32_t *d_entries = nullptr;   // per pose: entry_cap tile-list entries (record index | quadrant mask << 28)
@@ -1268,7 +1361,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
 
 void rdoom_batch_destroy(rdoom_batch *b) {
   if (!b) return;
-  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries,
+  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_tmp_recs, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries,
                   (void *)b->d_overflow, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb})
     if (p) (void)hipFree(p);
@@ -1295,9 +1388,11 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   const size_t npx = (size_t)width * height * max_poses;
   hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_tmp_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_sorted, sizeof(uint4) * (size_t)b->cap * max_poses);
   b->n_tiles = ((width + TILE_W - 1) / TILE_W) * ((height + TILE_H - 1) / TILE_H);
-  b->entry_cap = std::max<uint32_t>(65536u, 32u * b->n_tiles);
+  b->entry_cap = std::max<uint32_t>(65536u, 32u * b->n_tiles);  // tile-list entries per pose; beyond it the pose is scanned
+  if (const char *dbg = getenv("RDOOM_ENTRY_CAP")) b->entry_cap = (uint32_t)std::max(1, atoi(dbg));  // tests: force that fallback
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_tile_hdr, sizeof(uint2) * (size_t)b->n_tiles * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_entries, sizeof(uint32_t) * (size_t)b->entry_cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_overflow, sizeof(uint32_t) * max_poses);
@@ -1346,13 +1441,15 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   const int W = (int)b->width, H = (int)b->height;
   if (lv->ntri) {
     hipLaunchKernelGGL(setup_kernel, dim3(n), dim3(256), 0, st, lv->view, b->d_poses, W, H, kinds_mask, b->d_recs,
-                       b->d_sorted, b->d_counts, b->cap);
+                       b->d_tmp_recs, b->d_sorted, b->d_counts, b->cap);
   }
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   static const bool no_bins = getenv("RDOOM_NO_BINS") != nullptr;  // debug: exercise the fallback scan
   if (lv->ntri && !no_bins) {
-    hipLaunchKernelGGL(bin_kernel, dim3(n), dim3(BIN_THREADS), 0, st, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x,
-                       tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow);
+    const uint32_t bin_tiles = std::min<uint32_t>((uint32_t)(tiles_x * tiles_y), MAX_TILES);
+    hipLaunchKernelGGL(bin_kernel, dim3(n), dim3(BIN_THREADS), 2 * sizeof(uint32_t) * bin_tiles, st, b->d_recs,
+                       b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap,
+                       b->d_overflow);
   } else {
     HIP_TRY(hipMemsetAsync(b->d_overflow, 0xFF, sizeof(uint32_t) * n, st));
     if (!lv->ntri) HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
@@ -1362,7 +1459,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
   static const bool want_stats = getenv("RDOOM_STATS") != nullptr;
   if (want_stats) {
-    unsigned long long *d_stats = nullptr, h[10];
+    unsigned long long *d_stats = nullptr, h[16];
     HIP_TRY(hipMalloc((void **)&d_stats, sizeof h));
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof h, st));
     hipLaunchKernelGGL(raster_kernel<true>, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs,
@@ -1373,10 +1470,11 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     const double waves = (double)nblocks * 4.0;
     fprintf(stderr,
             "[rdoom stats] per wave: queue %.1f  quadrant-bbox %.1f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
-            "  general %.1f (lanes %.1f) | coarse tests/block %.0f hits %.1f\n",
+            "  general %.2f (lanes %.1f: zrange %.1f, rw<=0 %.1f, masked %.1f, tie %.1f) | coarse tests/block %.0f hits %.1f\n",
             h[0] / waves, h[1] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
             h[4] ? (double)h[5] / h[4] : 0.0, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
-            (double)h[8] / (double)nblocks, (double)h[9] / (double)nblocks);
+            h[6] ? (double)h[10] / h[6] : 0.0, h[6] ? (double)h[11] / h[6] : 0.0, h[6] ? (double)h[12] / h[6] : 0.0,
+            h[6] ? (double)h[13] / h[6] : 0.0, (double)h[8] / (double)nblocks, (double)h[9] / (double)nblocks);
   } else {
     hipLaunchKernelGGL(raster_kernel<false>, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs,
                        b->d_sorted, b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,

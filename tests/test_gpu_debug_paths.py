@@ -3,7 +3,8 @@
   RDOOM_DEBUG_LEAK_MOD=n  every n-th pixel is treated as an alpha leak, so fixup_kernel's general per-pixel
                           rule (all candidates of the tile, lexicographic (depth, primitive) minimum) re-resolves
                           ordinary pixels -- output must be unchanged;
-  RDOOM_NO_BINS=1         the rasteriser's fallback scan (no per-tile bins), as used when a pose overflows them."""
+  RDOOM_NO_BINS=1         the rasteriser's fallback scan (no per-tile bins), as used when a pose overflows them;
+  RDOOM_ENTRY_CAP=n       tile-list entries per pose the binning kernel may emit, to force that overflow."""
 import os
 import re
 import subprocess
@@ -32,6 +33,12 @@ def test_forced_alpha_leak_fixups_do_not_change_the_image():
 
 def test_fallback_scan_without_bins():
     bad, _ = run_child({'RDOOM_NO_BINS': '1'})
+    assert bad == 0
+
+
+def test_tile_list_overflow_falls_back_to_the_scan():
+    """RDOOM_ENTRY_CAP=300: nearly every pose needs more tile-list entries than that, sets its overflow flag and is rasterised by the scan"""
+    bad, _ = run_child({'RDOOM_ENTRY_CAP': '300'})
     assert bad == 0
 
 
