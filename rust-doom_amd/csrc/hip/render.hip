@@ -578,7 +578,7 @@ __device__ __forceinline__ uint32_t load_texel(const DeviceLevelView &lv, const 
 // XCD's L2.
 // =================================================================================================
 template <bool STATS>
-__global__ __launch_bounds__(256, 5) void raster_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+__global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                      const uint4 *__restrict__ sorted,
                                                      const uint32_t *__restrict__ counts, uint32_t cap,
                                                      uint32_t n_poses, int width, int height, int tiles_x,
@@ -687,19 +687,31 @@ __global__ __launch_bounds__(256, 5) void raster_kernel(DeviceLevelView lv, cons
       const float e0a = r.e[0], e0b = r.e[1], e0c = r.e[2], e1a = r.e[3], e1b = r.e[4], e1c = r.e[5], e2a = r.e[6],
                   e2b = r.e[7], e2c = r.e[8];
       const float za = r.zp[0], zb = r.zp[1], zc = r.zp[2];
-      // lane-level exact rejection: largest edge values and nearest depth over my 4x4 block
+      // lane-level exact rejection over my 4x4 block.  Early-z first (most rejected triangles are simply hidden):
+      // nearest depth of the plane over the block against the farthest depth I still hold
+      const float zn = fmaf(za, za > 0.0f ? pxlo : pxhi, fmaf(zb, zb > 0.0f ? pylo : pyhi, zc));
+      const uint32_t dn = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
+      const bool zpass = (zn <= 1.0f) & (dn <= lane_far);
+      if (!__any(zpass)) {
+        if (STATS) st[15]++;
+        continue;
+      }
+      // largest edge values and farthest depth
       const float m0 = fmaf(e0a, e0a > 0.0f ? pxhi : pxlo, fmaf(e0b, e0b > 0.0f ? pyhi : pylo, e0c));
       const float m1 = fmaf(e1a, e1a > 0.0f ? pxhi : pxlo, fmaf(e1b, e1b > 0.0f ? pyhi : pylo, e1c));
       const float m2 = fmaf(e2a, e2a > 0.0f ? pxhi : pxlo, fmaf(e2b, e2b > 0.0f ? pyhi : pylo, e2c));
-      const float zn = fmaf(za, za > 0.0f ? pxlo : pxhi, fmaf(zb, zb > 0.0f ? pylo : pyhi, zc));
       const float zf = fmaf(za, za > 0.0f ? pxhi : pxlo, fmaf(zb, zb > 0.0f ? pyhi : pylo, zc));
-      const uint32_t dn = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
-      const bool need = bx <= x1 && bx + 3 >= x0 && by <= y1 && by + 3 >= y0 && m0 >= 0.0f && m1 >= 0.0f &&
-                        m2 >= 0.0f && zn <= 1.0f && zf >= 0.0f && dn <= lane_far;
-      if (!__any(need)) continue;
-      if (STATS) st[2]++, st[3] += (unsigned long long)__popcll(__ballot(need));
+      const bool need0 = zpass && bx <= x1 && bx + 3 >= x0 && by <= y1 && by + 3 >= y0 && m0 >= 0.0f && m1 >= 0.0f &&
+                         m2 >= 0.0f && zf >= 0.0f;
+      if (STATS && !__any(need0)) st[14]++;
+      if (!__any(need0)) continue;
       const uint32_t ridx = qe & 0x0FFFFFFFu;
       const float wa = r.wp[0], wb = r.wp[1], wc = r.wp[2];
+      // R3 needs rw > 0: a block whose largest 1/w is not positive holds no coverable pixel (same corner argument)
+      const float rwf = fmaf(wa, wa > 0.0f ? pxhi : pxlo, fmaf(wb, wb > 0.0f ? pyhi : pylo, wc));
+      const bool need = need0 & (rwf > 0.0f);
+      if (!__any(need)) continue;
+      if (STATS) st[2]++, st[3] += (unsigned long long)__popcll(__ballot(need));
       // Fast path (exact): block fully inside the bbox, whole block inside the depth range and in front
       // of the eye, texture rectangle fully opaque.  Edge ties and depth ties are only *detected* here and
       // replayed through the general path below, so the result is the same as running it everywhere.
@@ -892,6 +904,7 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
 // idx / d for idx < 2^24 by multiply-high (m, sh) computed and verified on the host
 __device__ __forceinline__ uint32_t fast_div(uint32_t idx, uint32_t m, uint32_t sh) { return __umulhi(idx, m) >> sh; }
 
+template <int FRAG_GROUP, int DBG>  // FRAG_GROUP: slabs whose visibility loads are in flight together; DBG: timing experiments only
 __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
                                                        const uint32_t *__restrict__ vis, uint32_t n_poses,
@@ -950,11 +963,21 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
       if (k == 0) pfb[qi] = v;
     }
   };
-  for (int it = 0; it < FRAG_CHUNK; it++) {
-    const uint32_t qi = (chunk * FRAG_CHUNK + (uint32_t)it) * 256u + threadIdx.x;
-    if (qi - lane >= quads_per_pose) break;  // wave-uniform: the whole wave is past the end of the frame
+  // The visibility words of FRAG_GROUP slabs are requested back to back (they stream from HBM; the record and
+  // texel gathers behind them hit L2), so one HBM latency is paid per group instead of per slab.
+  for (int it0 = 0; it0 < FRAG_CHUNK; it0 += FRAG_GROUP) {
+    if ((chunk * FRAG_CHUNK + (uint32_t)it0) * 256u + (threadIdx.x - lane) >= quads_per_pose) break;  // wave-uniform
+    uint4 idsv[FRAG_GROUP];
+#pragma unroll
+    for (int u = 0; u < FRAG_GROUP; u++) {
+      const uint32_t q = (chunk * FRAG_CHUNK + (uint32_t)(it0 + u)) * 256u + threadIdx.x;
+      idsv[u] = q < quads_per_pose ? ((DBG & 1) ? make_uint4(q & 63u, q & 63u, q & 63u, q & 63u) : pvis[q]) : make_uint4(NONE, NONE, NONE, NONE);
+    }
+#pragma unroll
+    for (int u = 0; u < FRAG_GROUP; u++) {
+    const uint32_t qi = (chunk * FRAG_CHUNK + (uint32_t)(it0 + u)) * 256u + threadIdx.x;
     const bool valid = qi < quads_per_pose;
-    const uint4 ids = valid ? pvis[qi] : make_uint4(NONE, NONE, NONE, NONE);
+    const uint4 ids = idsv[u];
     const bool uniform = (ids.x == ids.y) & (ids.y == ids.z) & (ids.z == ids.w);
     bool done = false;
     uint32_t out = 0;
@@ -1016,10 +1039,10 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
         const uint32_t o1 = (((uint32_t)cvt_floor_i32(uya.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxa.y) & wm);
         const uint32_t o2 = (((uint32_t)cvt_floor_i32(uyb.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxb.x) & wm);
         const uint32_t o3 = (((uint32_t)cvt_floor_i32(uyb.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxb.y) & wm);
-        const uint32_t t0 = *reinterpret_cast<const uint16_t *>(tb + (o0 * 2u + base2)),
-                       t1 = *reinterpret_cast<const uint16_t *>(tb + (o1 * 2u + base2)),
-                       t2 = *reinterpret_cast<const uint16_t *>(tb + (o2 * 2u + base2)),
-                       t3 = *reinterpret_cast<const uint16_t *>(tb + (o3 * 2u + base2));
+        const uint32_t t0 = (DBG & 2) ? (o0 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o0 * 2u + base2)),
+                       t1 = (DBG & 2) ? (o1 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o1 * 2u + base2)),
+                       t2 = (DBG & 2) ? (o2 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o2 * 2u + base2)),
+                       t3 = (DBG & 2) ? (o3 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o3 * 2u + base2));
         // F4, F5 at the two end pixels; the middle pixels only when the ends disagree
         auto rows_of = [&](f32x2 dist) {
           const f32x2 dterm = splat(1.0f) - exact_div09_2(dist + splat(0.9f));
@@ -1051,6 +1074,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
         wn -= 16u;
         shade_listed(wn, 16u);
       }
+    }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1470,11 +1494,12 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     const double waves = (double)nblocks * 4.0;
     fprintf(stderr,
             "[rdoom stats] per wave: queue %.1f  quadrant-bbox %.1f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
-            "  general %.2f (lanes %.1f: zrange %.1f, rw<=0 %.1f, masked %.1f, tie %.1f) | coarse tests/block %.0f hits %.1f\n",
+            "  general %.2f (lanes %.1f: zrange %.1f, rw<=0 %.1f, masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | coarse tests/block %.0f hits %.1f\n",
             h[0] / waves, h[1] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
             h[4] ? (double)h[5] / h[4] : 0.0, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
             h[6] ? (double)h[10] / h[6] : 0.0, h[6] ? (double)h[11] / h[6] : 0.0, h[6] ? (double)h[12] / h[6] : 0.0,
-            h[6] ? (double)h[13] / h[6] : 0.0, (double)h[8] / (double)nblocks, (double)h[9] / (double)nblocks);
+            h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, (double)h[8] / (double)nblocks,
+            (double)h[9] / (double)nblocks);
   } else {
     hipLaunchKernelGGL(raster_kernel<false>, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs,
                        b->d_sorted, b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
@@ -1501,7 +1526,13 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   HIP_TRY(hipMemsetAsync(b->d_fix_count, 0, 2 * sizeof(uint32_t), st));
   const uint64_t fgrid = (uint64_t)((n + 7) / 8) * 8ull * fblocks;
   if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
-  hipLaunchKernelGGL(fragment_kernel, dim3((uint32_t)fgrid), dim3(256), 0, st, lv->view, b->d_recs, b->cap, b->d_poses,
+  static const int frag_group = getenv("RDOOM_FRAG_GROUP") ? atoi(getenv("RDOOM_FRAG_GROUP")) : 1;  // tuning switch
+  static const int frag_dbg = getenv("RDOOM_FRAG_DBG") ? atoi(getenv("RDOOM_FRAG_DBG")) : 0;  // timing experiments (wrong images)
+  auto frag = frag_group == 4 ? fragment_kernel<4, 0> : (frag_group == 2 ? fragment_kernel<2, 0> : fragment_kernel<1, 0>);
+  if (frag_dbg == 1) frag = fragment_kernel<1, 1>;
+  if (frag_dbg == 2) frag = fragment_kernel<1, 2>;
+  if (frag_dbg == 3) frag = fragment_kernel<1, 3>;
+  hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv->view, b->d_recs, b->cap, b->d_poses,
                      b->d_vis, n, fblocks, qpp, qpr, div_m, div_sh, W, H, b->d_fb, b->d_fix_count, b->d_fix_list,
                      b->fix_cap, debug_leak_mod);
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap,
