@@ -43,7 +43,7 @@ def main():
     ap.add_argument('--level', type=int, default=0)
     ap.add_argument('--iwad', default=None)
     ap.add_argument('--metadata', default=None)
-    ap.add_argument('--cpu-sample', type=int, default=16, help='poses rendered by the CPU oracle (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=512, help='poses rendered by the CPU oracle (0 = skip)')
     args = ap.parse_args()
 
     import torch
