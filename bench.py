@@ -133,7 +133,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32+u8', 'data': 'synthetic',
             'frames_per_s': round(args.poses * args.steps * world / elapsed, 1),
             'config': {'workload': 'E1M1 (synthetic IWAD, tools/mkwad.py) %d-pose sweep at %dx%d per GPU, '
-                                   'walls+flats+sky' % (args.poses, args.width, args.height),
+                                   'walls+flats+decor+sky' % (args.poses, args.width, args.height),
                        'poses_per_gpu': args.poses, 'width': args.width, 'height': args.height,
                        'visible_triangles_per_pose': round(vis_tris / args.poses, 1),
                        'alpha_leak_fixup_pixels_per_step': fixups,

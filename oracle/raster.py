@@ -27,7 +27,9 @@ class _Level(ctypes.Structure):
                 ('flat_atlas', ctypes.c_void_p), ('flat_w', ctypes.c_uint32), ('flat_h', ctypes.c_uint32),
                 ('wall_atlas', ctypes.c_void_p), ('wall_w', ctypes.c_uint32), ('wall_h', ctypes.c_uint32),
                 ('sky_tex', ctypes.c_void_p), ('sky_w', ctypes.c_uint32), ('sky_h', ctypes.c_uint32),
-                ('sky_band', ctypes.c_float), ('colormap', ctypes.c_void_p)]
+                ('sky_band', ctypes.c_float), ('colormap', ctypes.c_void_p),
+                ('decor_verts', ctypes.c_void_p), ('decor_indices', ctypes.c_void_p),
+                ('decor_atlas', ctypes.c_void_p), ('decor_w', ctypes.c_uint32), ('decor_h', ctypes.c_uint32)]
 
 
 _lib = None
@@ -50,23 +52,29 @@ class RasterOracle:
     a dict with the same keys) and renders poses on the CPU."""
 
     def __init__(self, lvl):
-        g = (lambda k: lvl[k]) if isinstance(lvl, dict) else (lambda k: getattr(lvl, k))
+        g = (lambda k, d=None: lvl.get(k, d)) if isinstance(lvl, dict) else (lambda k, d=None: getattr(lvl, k, d))
         c = np.ascontiguousarray
         self._keep = dict(
             sv=c(g('static_vertices')), si=c(g('static_indices'), np.uint32),
             kv=c(g('sky_vertices'), np.float32), ki=c(g('sky_indices'), np.uint32),
             dr=c(g('draws'), np.uint32), fa=c(g('flat_atlas'), np.uint8), wa=c(g('wall_atlas'), np.uint16),
-            st=c(g('sky_texture'), np.uint16), cm=c(g('colormap'), np.uint8))
+            st=c(g('sky_texture'), np.uint16), cm=c(g('colormap'), np.uint8),
+            dv=c(g('decor_vertices', np.zeros(0, np.uint8))), di=c(g('decor_indices', np.zeros(0, np.uint32)), np.uint32),
+            da=c(g('decor_atlas', np.zeros((0, 0), np.uint16)), np.uint16))
         k = self._keep
         assert k['sv'].dtype.itemsize == 48 and k['cm'].size == 32 * 256
-        for a in (k['fa'], k['wa']):
+        assert k['dv'].size == 0 or k['dv'].dtype.itemsize == 44, 'decor vertices must be 44-byte SpriteVertex records'
+        for a in (k['fa'], k['wa'], k['da']):
             for d in a.shape:
                 assert d == 0 or (d & (d - 1)) == 0, 'atlas sizes must be powers of two'
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         self.level = _Level(p(k['sv']), p(k['si']), p(k['kv']), p(k['ki']), p(k['dr']), len(k['dr']),
                             p(k['fa']), k['fa'].shape[1] if k['fa'].ndim == 2 else 0, k['fa'].shape[0],
                             p(k['wa']), k['wa'].shape[1] if k['wa'].ndim == 2 else 0, k['wa'].shape[0],
-                            p(k['st']), k['st'].shape[1], k['st'].shape[0], float(g('sky_band')), p(k['cm']))
+                            p(k['st']), k['st'].shape[1], k['st'].shape[0], float(g('sky_band')), p(k['cm']),
+                            p(k['dv']), p(k['di']), p(k['da']),
+                            k['da'].shape[1] if k['da'].ndim == 2 and k['da'].size else 0,
+                            k['da'].shape[0] if k['da'].ndim == 2 and k['da'].size else 0)
 
     def render(self, modelview, projection, time, lights, width, height, kinds=ALL_KINDS, want_prim=False):
         lib = _load()

@@ -9,6 +9,8 @@
  *   - fragment stage    assets/shaders/static.frag:18-28 with samplers game_shaders.rs:133-142
  *                       (palette CLAMP/NEAREST) and :395-404 (atlas REPEAT/NEAREST)
  *   - sky               assets/shaders/sky.vert:9-16, sky.frag:12-26 (KIND_SKY)
+ *   - decor billboards  assets/shaders/sprite.vert:23-47, sprite.frag:15-27 (KIND_DECOR), vertex layout
+ *                       game/src/vertex.rs:30-40, quad emission game/src/level.rs:764-793
  *
  * OpenGL leaves sub-ulp behaviour to the driver, so "the arithmetic" is pinned HERE and in
  * DESIGN.md section "Raster arithmetic" -- binary32, explicit operation order, fmaf only where
@@ -41,6 +43,17 @@ typedef struct {
 } StaticVertex; /* game/src/vertex.rs:5-16, 48 bytes */
 
 typedef struct {
+  float a_pos[3];
+  float a_atlas_uv[2];
+  float a_tile_uv[2];
+  float a_tile_size[2];
+  float a_local_x;
+  uint8_t a_num_frames;
+  uint8_t a_light;
+  uint8_t pad[2];
+} SpriteVertex; /* game/src/vertex.rs:30-40, 44 bytes */
+
+typedef struct {
   uint32_t kind, object_id, first_index, index_count;
 } Draw;
 
@@ -59,6 +72,10 @@ typedef struct {
   uint32_t sky_w, sky_h;
   float sky_band;
   const uint8_t *colormap; /* 32*256 */
+  const SpriteVertex *decor_verts;
+  const uint32_t *decor_indices;
+  const uint16_t *decor_atlas;
+  uint32_t decor_w, decor_h;
 } OracleLevel;
 
 typedef struct {
@@ -178,6 +195,9 @@ static uint32_t fetch_texel(const OracleLevel *L, const Setup *s, float px, floa
   if (s->kind == KIND_FLAT) {
     return L->flat_atlas[(size_t)(iy & (int)(L->flat_h - 1)) * L->flat_w + (size_t)(ix & (int)(L->flat_w - 1))];
   }
+  if (s->kind == KIND_DECOR) {
+    return L->decor_atlas[(size_t)(iy & (int)(L->decor_h - 1)) * L->decor_w + (size_t)(ix & (int)(L->decor_w - 1))];
+  }
   return L->wall_atlas[(size_t)(iy & (int)(L->wall_h - 1)) * L->wall_w + (size_t)(ix & (int)(L->wall_w - 1))];
 }
 
@@ -188,6 +208,44 @@ static uint8_t shade(const OracleLevel *L, uint32_t idx, float v_light, float di
   float t = (1.0f - light) * 32.0f;
   int row = t < 0.0f ? 0 : (t >= 32.0f ? 31 : (int)floorf(t));
   return L->colormap[row * 256 + (int)idx];
+}
+
+/* sprite.frag:22-25: DIST_SCALE = 1.0, light = min(v_light, v_light * LIGHT_SCALE - dist_term) */
+static uint8_t shade_decor(const OracleLevel *L, uint32_t idx, float v_light, float dist) {
+  float dist_term = fminf(1.0f, 1.0f - 1.0f / (dist + 1.0f));
+  float light = fminf(v_light, v_light * 2.0f - dist_term);
+  float t = (1.0f - light) * 32.0f;
+  int row = t < 0.0f ? 0 : (t >= 32.0f ? 31 : (int)floorf(t));
+  return L->colormap[row * 256 + (int)idx];
+}
+
+/* sprite.vert:27-39: animation-frame atlas offset; rows advance by a_tile_size.y (not a row height) */
+static void sprite_atlas_uv_at(const SpriteVertex *v, float time, float atlas_w, float *au, float *av) {
+  if (v->a_num_frames == 1) {
+    *au = v->a_atlas_uv[0];
+    *av = v->a_atlas_uv[1];
+    return;
+  }
+  const float anim_fps = 8.0f / 35.0f;
+  float frame_index = time / anim_fps;
+  frame_index = floorf(glsl_mod(frame_index, (float)v->a_num_frames));
+  float atlas_u = v->a_atlas_uv[0] + frame_index * v->a_tile_size[0];
+  float n_rows_down = ceilf((atlas_u + v->a_tile_size[0]) / atlas_w) - 1.0f;
+  atlas_u = atlas_u + glsl_mod(atlas_w - v->a_atlas_uv[0], v->a_tile_size[0]) * n_rows_down;
+  *au = atlas_u;
+  *av = v->a_atlas_uv[1] + n_rows_down * v->a_tile_size[1];
+}
+
+/* sprite.vert:41-46: pos = a_pos + right * a_local_x with right = row 0 of the modelview;
+ * projected = u_projection * (u_modelview * vec4(pos, 1)) -- NOT (P*M)*v as in static.vert.
+ * Pinned arithmetic: p_i = fma(right_i, local_x, a_pos_i); eye and clip as fma chains. */
+static void xform_decor(const float *m, const float *p, const SpriteVertex *v, float *clip) {
+  float pos[3], eye[4];
+  for (int i = 0; i < 3; i++) pos[i] = fmaf(m[4 * i], v->a_local_x, v->a_pos[i]);
+  for (int r = 0; r < 4; r++)
+    eye[r] = fmaf(m[8 + r], pos[2], fmaf(m[4 + r], pos[1], fmaf(m[0 + r], pos[0], m[12 + r])));
+  for (int r = 0; r < 4; r++)
+    clip[r] = fmaf(p[12 + r], eye[3], fmaf(p[8 + r], eye[2], fmaf(p[4 + r], eye[1], p[0 + r] * eye[0])));
 }
 
 /* sky.frag:12-26.  v_p = clip position interpolated (x/w, y/w are NDC), v_r flat per pose. */
@@ -238,7 +296,7 @@ static int render_with_scratch(const OracleLevel *L, const float *modelview, con
   for (uint32_t d = 0; d < L->n_draws; d++) {
     const Draw *dr = &L->draws[d];
     uint32_t ntri = dr->index_count / 3;
-    if (!((kinds_mask >> dr->kind) & 1u) || dr->kind == KIND_DECOR) {
+    if (!((kinds_mask >> dr->kind) & 1u) || dr->kind > KIND_SKY) {
       prim_id += ntri;
       continue;
     }
@@ -248,6 +306,19 @@ static int render_with_scratch(const OracleLevel *L, const float *modelview, con
       s.kind = dr->kind;
       if (dr->kind == KIND_SKY) {
         for (int i = 0; i < 3; i++) xform(pm, &L->sky_verts[3 * L->sky_indices[dr->first_index + 3 * t + i]], clip[i]);
+      } else if (dr->kind == KIND_DECOR) {
+        const SpriteVertex *vv[3];
+        for (int i = 0; i < 3; i++) {
+          vv[i] = &L->decor_verts[L->decor_indices[dr->first_index + 3 * t + i]];
+          xform_decor(modelview, projection, vv[i], clip[i]);
+          u[i] = vv[i]->a_tile_uv[0]; /* sprite.vert:24: no scroll */
+          v[i] = vv[i]->a_tile_uv[1];
+        }
+        const SpriteVertex *pv = vv[2];
+        sprite_atlas_uv_at(pv, time, (float)L->decor_w, &s.atlas_u, &s.atlas_v);
+        s.size_x = pv->a_tile_size[0];
+        s.size_y = pv->a_tile_size[1];
+        s.light = (float)lights[pv->a_light] / 255.0f;
       } else {
         const StaticVertex *vv[3];
         for (int i = 0; i < 3; i++) {
@@ -287,8 +358,9 @@ static int render_with_scratch(const OracleLevel *L, const float *modelview, con
           } else {
             float dist;
             uint32_t texel = fetch_texel(L, &s, px, py, &dist);
-            if (dr->kind == KIND_WALL && (texel & 0x8000u)) continue; /* static.frag:21 discard */
-            colour = shade(L, texel & 0xFFu, s.light, dist);
+            if (dr->kind != KIND_FLAT && (texel & 0x8000u)) continue; /* static.frag:21 / sprite.frag:20 discard */
+            colour = dr->kind == KIND_DECOR ? shade_decor(L, texel & 0xFFu, s.light, dist)
+                                            : shade(L, texel & 0xFFu, s.light, dist);
           }
           depth[o] = d24;
           prim[o] = prim_id;

@@ -34,18 +34,19 @@ constexpr int QCAP = 64;
 struct alignas(16) LevelTri {  // 96 bytes
   float pos[9];
   float uv[6];
-  float scroll[3];
+  float scroll[3];              // a_scroll_rate per vertex; for decor triangles: a_local_x per vertex
   float atlas_u, atlas_v, size_x, size_y, row_height;
   uint32_t packed;  // num_frames | light << 8 | kind << 16 | masked border << 18 | masked interior << 19
 };
 static_assert(sizeof(LevelTri) == 96, "LevelTri layout");
 
-struct alignas(16) PoseConst {  // 336 bytes
+struct alignas(16) PoseConst {  // 464 bytes
   float pm[16];                 // projection * modelview (V1)
   float time, vr0, vr1, pad;
   uint8_t lights[256];
+  float mv[16], proj[16];       // the two uniforms themselves: sprite.vert transforms in two steps (D1..D3)
 };
-static_assert(sizeof(PoseConst) == 336, "PoseConst layout");
+static_assert(sizeof(PoseConst) == 464, "PoseConst layout");
 
 // ---- per (pose, visible triangle) records -----------------------------------------------------
 struct alignas(16) RasterRec {  // 80 bytes
@@ -88,9 +89,10 @@ struct DeviceLevelView {
   // one u16 texel store: the wall atlas (lo = palette index, bit 15 = transparent) followed, at element
   // flat_base (a multiple of 1024), by the flat atlas promoted to u16 (hi byte 0: never transparent)
   const uint16_t *texels;
-  uint32_t flat_base;
+  uint32_t flat_base, decor_base;  // the decor (sprite) atlas follows the flats, also at a multiple of 1024
   uint32_t flat_w, flat_h;
   uint32_t wall_w, wall_h;
+  uint32_t decor_w, decor_h;
   const uint16_t *sky_tex;
   uint32_t sky_w, sky_h;
   float sky_band;
@@ -126,23 +128,37 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
   if (ok) {
     const LevelTri tri = lv.tris[t];
     const uint32_t kind = (tri.packed >> 16) & 3u;
-    ok = ((kinds_mask >> kind) & 1u) && kind != RDOOM_KIND_DECOR;
+    ok = ((kinds_mask >> kind) & 1u) != 0u;
     if (ok) {
       float clip[3][4], u[3], v[3];
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         const float x = tri.pos[3 * i], y = tri.pos[3 * i + 1], z = tri.pos[3 * i + 2];
+        if (kind == RDOOM_KIND_DECOR) {
+          // D1..D3 (sprite.vert:41-46): camera-facing expansion along row 0 of the modelview, then
+          // projection * (modelview * pos) in two steps
+          const float lx = tri.scroll[i];
+          const float px = fmaf(pc.mv[0], lx, x), py = fmaf(pc.mv[4], lx, y), pz = fmaf(pc.mv[8], lx, z);
+          float eye[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-          clip[i][r] = fmaf(pc.pm[8 + r], z, fmaf(pc.pm[4 + r], y, fmaf(pc.pm[r], x, pc.pm[12 + r])));
-        u[i] = tri.uv[2 * i] + pc.time * tri.scroll[i];
+          for (int r = 0; r < 4; r++) eye[r] = fmaf(pc.mv[8 + r], pz, fmaf(pc.mv[4 + r], py, fmaf(pc.mv[r], px, pc.mv[12 + r])));
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            clip[i][r] = fmaf(pc.proj[12 + r], eye[3], fmaf(pc.proj[8 + r], eye[2], fmaf(pc.proj[4 + r], eye[1], pc.proj[r] * eye[0])));
+          u[i] = tri.uv[2 * i];  // sprite.vert:24: no scroll
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            clip[i][r] = fmaf(pc.pm[8 + r], z, fmaf(pc.pm[4 + r], y, fmaf(pc.pm[r], x, pc.pm[12 + r])));
+          u[i] = tri.uv[2 * i] + pc.time * tri.scroll[i];
+        }
         v[i] = tri.uv[2 * i + 1];
       }
       // flat varyings (provoking vertex data were folded into LevelTri on the host)
       const uint32_t nframes = tri.packed & 0xFFu;
       float au = tri.atlas_u, av = tri.atlas_v;
       if (nframes != 1u && kind != RDOOM_KIND_SKY) {
-        const float aw = kind == RDOOM_KIND_FLAT ? (float)lv.flat_w : (float)lv.wall_w;
+        const float aw = kind == RDOOM_KIND_FLAT ? (float)lv.flat_w : (kind == RDOOM_KIND_DECOR ? (float)lv.decor_w : (float)lv.wall_w);
         const float anim_fps = 8.0f / 35.0f;
         float fi = pc.time / anim_fps;
         fi = floorf(glsl_mod(fi, (float)nframes));
@@ -227,15 +243,17 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
           sr.light = (float)pc.lights[(tri.packed >> 8) & 0xFFu] / 255.0f;
           const uint32_t bx = __float_as_uint(tri.size_x), by = __float_as_uint(tri.size_y);
           const bool p2x = (bx & 0x7FFFFFu) == 0u && tri.size_x > 0.0f, p2y = (by & 0x7FFFFFu) == 0u && tri.size_y > 0.0f;
-          const bool is_flat = kind == RDOOM_KIND_FLAT;
-          const uint32_t aw = is_flat ? lv.flat_w : lv.wall_w, ah = is_flat ? lv.flat_h : lv.wall_h;
+          const bool is_flat = kind == RDOOM_KIND_FLAT, is_decor = kind == RDOOM_KIND_DECOR;
+          const uint32_t aw = is_flat ? lv.flat_w : (is_decor ? lv.decor_w : lv.wall_w);
+          const uint32_t ah = is_flat ? lv.flat_h : (is_decor ? lv.decor_h : lv.wall_h);
+          const uint32_t tbase = is_flat ? lv.flat_base : (is_decor ? lv.decor_base : 0u);
           const uint32_t lw = aw ? 31u - (uint32_t)__clz(aw) : 0u;
           auto packed_ok = [](float sz, bool p2) {
             return p2 ? (sz >= 0x1p-20f && sz <= 0x1p20f) : (sz >= 1.0f && sz <= 4096.0f && floorf(sz) == sz);
           };
-          const bool fast_ok = packed_ok(tri.size_x, p2x) && packed_ok(tri.size_y, p2y) && kind != RDOOM_KIND_SKY;
+          const bool fast_ok = packed_ok(tri.size_x, p2x) && packed_ok(tri.size_y, p2y) && kind <= RDOOM_KIND_WALL;
           sr.flags = kind | (p2x ? SHADE_POW2_X : 0u) | (p2y ? SHADE_POW2_Y : 0u) | (fast_ok ? SHADE_FAST : 0u) |
-                     ((p2x && p2y) ? 0u : SHADE_NP2) | (lw << 8) | (((is_flat ? lv.flat_base : 0u) >> 10) << 16);
+                     ((p2x && p2y) ? 0u : SHADE_NP2) | (lw << 8) | ((tbase >> 10) << 16);
           sr.tex = kind == RDOOM_KIND_SKY ? 0u : (((aw - 1u) & 0xFFFFu) | (((ah - 1u) & 0xFFFFu) << 16));
         }
       }
@@ -893,9 +911,15 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
   if (kind == RDOOM_KIND_SKY) return shade_sky(lv, cmap, px, py, width, height, pc.vr0, pc.vr1);
   const TexelAt t = texel_coords(s, px, row_w, row_u, row_v);
   const uint32_t texel = load_texel(lv, s, t.ix, t.iy);
-  if (kind == RDOOM_KIND_WALL && (texel & 0x8000u)) return 0x100u;
-  const float dist_term = fminf(1.0f, 1.0f - 0.9f / (t.dist + 0.9f));
-  const float light = s.light * 2.0f - dist_term;
+  if (kind != RDOOM_KIND_FLAT && (texel & 0x8000u)) return 0x100u;
+  float light;
+  if (kind == RDOOM_KIND_DECOR) {  // sprite.frag:22-25: DIST_SCALE = 1, light = min(v_light, 2 v_light - dist_term)
+    const float dist_term = fminf(1.0f, 1.0f - 1.0f / (t.dist + 1.0f));
+    light = fminf(s.light, s.light * 2.0f - dist_term);
+  } else {
+    const float dist_term = fminf(1.0f, 1.0f - 0.9f / (t.dist + 0.9f));
+    light = s.light * 2.0f - dist_term;
+  }
   const float tt = (1.0f - light) * 32.0f;
   const int rowc = tt < 0.0f ? 0 : (tt >= 32.0f ? 31 : (int)floorf(tt));
   return cmap[rowc * 256 + (int)(texel & 0xFFu)];
@@ -1248,7 +1272,10 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
     return rdoom::fail(RDOOM_BAD_ARG, "flat atlas %ux%u is not a power of two", d->flat_w, d->flat_h);
   if ((d->wall_w | d->wall_h) && !(is_pow2(d->wall_w) && is_pow2(d->wall_h)))
     return rdoom::fail(RDOOM_BAD_ARG, "wall atlas %ux%u is not a power of two", d->wall_w, d->wall_h);
-  if (d->flat_w > 32768 || d->flat_h > 32768 || d->wall_w > 32768 || d->wall_h > 32768)
+  if ((d->decor_w | d->decor_h) && !(is_pow2(d->decor_w) && is_pow2(d->decor_h)))
+    return rdoom::fail(RDOOM_BAD_ARG, "decor atlas %ux%u is not a power of two", d->decor_w, d->decor_h);
+  if (d->flat_w > 32768 || d->flat_h > 32768 || d->wall_w > 32768 || d->wall_h > 32768 || d->decor_w > 32768 ||
+      d->decor_h > 32768)
     return rdoom::fail(RDOOM_BAD_ARG, "atlas larger than 32768 texels on a side");
   // flatten the draws into one primitive list in draw order (primitive id == position)
   std::vector<LevelTri> tris;
@@ -1327,7 +1354,29 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
           if (idx >= d->n_sky_verts) return rdoom::fail(RDOOM_BAD_ARG, "draw %u: sky vertex out of bounds", di);
           std::memcpy(&lt.pos[3 * i], &d->sky_verts[3 * idx], 12);
         }
-      } else if (dr.kind != RDOOM_KIND_DECOR) {
+      } else if (dr.kind == RDOOM_KIND_DECOR) {
+        if ((uint64_t)dr.first_index + dr.index_count > d->n_decor_indices)
+          return rdoom::fail(RDOOM_BAD_ARG, "draw %u: decor index range out of bounds", di);
+        if (!d->decor_atlas) return rdoom::fail(RDOOM_BAD_ARG, "decor draw without a decor atlas");
+        const rdoom_sprite_vertex *vv[3];
+        for (int i = 0; i < 3; i++) {
+          const uint32_t idx = d->decor_indices[dr.first_index + 3 * t + i];
+          if (idx >= d->n_decor_verts) return rdoom::fail(RDOOM_BAD_ARG, "draw %u: decor vertex out of bounds", di);
+          vv[i] = &d->decor_verts[idx];
+          std::memcpy(&lt.pos[3 * i], vv[i]->a_pos, 12);
+          lt.uv[2 * i] = vv[i]->a_tile_uv[0];
+          lt.uv[2 * i + 1] = vv[i]->a_tile_uv[1];
+          lt.scroll[i] = vv[i]->a_local_x;  // decor triangles carry a_local_x here (sprite.vert:41-42)
+        }
+        const rdoom_sprite_vertex &pv = *vv[2];
+        lt.atlas_u = pv.a_atlas_uv[0];
+        lt.atlas_v = pv.a_atlas_uv[1];
+        lt.size_x = pv.a_tile_size[0];
+        lt.size_y = pv.a_tile_size[1];
+        lt.row_height = pv.a_tile_size[1];  // sprite.vert:37 advances animation rows by the tile height
+        // sprites are alpha tested per pixel (sprite.frag:20): always the exact path of the rasteriser
+        lt.packed = (uint32_t)pv.a_num_frames | ((uint32_t)pv.a_light << 8) | (dr.kind << 16) | (3u << 18);
+      } else {
         return rdoom::fail(RDOOM_BAD_ARG, "draw %u: unknown kind %u", di, dr.kind);
       }
       tris.push_back(lt);
@@ -1350,14 +1399,17 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
   // unified u16 texel store: wall atlas, then (at a multiple of 1024 elements) the flat atlas promoted to u16
   const size_t wall_n = d->wall_atlas ? (size_t)d->wall_w * d->wall_h : 0;
   const size_t flat_n = d->flat_atlas ? (size_t)d->flat_w * d->flat_h : 0;
+  const size_t decor_n = d->decor_atlas ? (size_t)d->decor_w * d->decor_h : 0;
   const size_t flat_base = (wall_n + 1023) / 1024 * 1024;
-  if (flat_base + flat_n >= ((size_t)1 << 26)) {
+  const size_t decor_base = (flat_base + flat_n + 1023) / 1024 * 1024;
+  if (decor_base + decor_n >= ((size_t)1 << 26)) {
     rdoom_level_destroy(lv);
-    return rdoom::fail(RDOOM_BAD_LEVEL, "atlases too large (%zu texels)", flat_base + flat_n);
+    return rdoom::fail(RDOOM_BAD_LEVEL, "atlases too large (%zu texels)", decor_base + decor_n);
   }
-  std::vector<uint16_t> texels(flat_base + flat_n + 1, 0);  // never empty: masked-off lanes read element 0
+  std::vector<uint16_t> texels(decor_base + decor_n + 1, 0);  // never empty: masked-off lanes read element 0
   if (wall_n) std::memcpy(texels.data(), d->wall_atlas, wall_n * 2);
   for (size_t i = 0; i < flat_n; i++) texels[flat_base + i] = d->flat_atlas[i];
+  if (decor_n) std::memcpy(texels.data() + decor_base, d->decor_atlas, decor_n * 2);
   if (e == hipSuccess) e = upload(&lv->d_wall, texels.data(), texels.size() * 2);
   if (e == hipSuccess) e = upload(&lv->d_sky, d->sky_texture, (size_t)d->sky_w * d->sky_h * 2);
   if (e == hipSuccess) e = upload(&lv->d_cmap, d->colormap, 32 * 256);
@@ -1370,6 +1422,9 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
   lv->view.ntri = lv->ntri;
   lv->view.texels = (const uint16_t *)lv->d_wall;
   lv->view.flat_base = (uint32_t)flat_base;
+  lv->view.decor_base = (uint32_t)decor_base;
+  lv->view.decor_w = d->decor_atlas ? d->decor_w : 0;
+  lv->view.decor_h = d->decor_atlas ? d->decor_h : 0;
   lv->view.flat_w = d->flat_w;
   lv->view.flat_h = d->flat_h;
   lv->view.wall_w = d->wall_w;
@@ -1452,6 +1507,8 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
         pc.pm[c * 4 + r] =
             ((P[0 * 4 + r] * M[c * 4 + 0] + P[1 * 4 + r] * M[c * 4 + 1]) + P[2 * 4 + r] * M[c * 4 + 2]) +
             P[3 * 4 + r] * M[c * 4 + 3];
+    std::memcpy(pc.mv, M, sizeof pc.mv);
+    std::memcpy(pc.proj, P, sizeof pc.proj);
     pc.time = poses[p].time;
     pc.vr0 = atan2f(pc.pm[8], pc.pm[10]);  // sky.vert:10-12
     pc.vr1 = pc.pm[9] / pc.pm[11];

@@ -84,3 +84,38 @@ def test_deterministic(oracle_levels):
     a = run_case(lv, 320, 200, 4, rd.ALL_KINDS)
     b = run_case(lv, 320, 200, 4, rd.ALL_KINDS)
     assert np.array_equal(a, b)
+
+
+def test_decor_billboards(oracle_levels):
+    """sprite.vert / sprite.frag: poses placed around decorations so that sprites fill part of
+    the frame; alpha-tested, camera-facing, lit with min(v_light, 2 v_light - dist_term)."""
+    lv = oracle_levels(0)
+    dv = lv.decor_vertices
+    assert len(dv) >= 8
+    w, h = 320, 200
+    poses = []
+    for q in range(0, len(dv) // 4, 2):
+        c = dv['a_pos'][4 * q:4 * q + 4].mean(0)
+        for ang in (0.3, 2.4, 4.5):
+            eye = c + np.array([np.sin(ang) * 1.3, 0.1, np.cos(ang) * 1.3])
+            d = c - eye
+            p = np.zeros(1, rd.POSE)[0]
+            p['modelview'] = view_matrix(eye, np.arctan2(-d[0], -d[2]), 0.05)
+            p['projection'] = reference_projection(w, h)
+            poses.append(p)
+    poses = np.array(poses[:24], rd.POSE)
+    lights = lv.lights.fill_buffer_at(0.0)
+    batch = rd.Batch(rd.DeviceLevel(lv), w, h, len(poses))
+    batch.enable_primitive_ids()
+    batch.render(poses, lights)
+    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    ro = raster.RasterOracle(lv)
+    first = np.cumsum([0] + [int(d[3]) // 3 for d in lv.draws])
+    decor_px = 0
+    for i in range(len(poses)):
+        ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], 0.0, lights, w, h, want_prim=True)
+        assert np.array_equal(oprim, prim[i]) and np.array_equal(ofb, fb[i]), i
+        for di, d in enumerate(lv.draws):
+            if d[0] == rd.KIND_DECOR:
+                decor_px += int(((oprim >= first[di]) & (oprim < first[di + 1])).sum())
+    assert decor_px > 10000  # the sprites really are in view
