@@ -68,7 +68,7 @@ def main():
     meta = args.metadata or META_PATH
     wad = rd.Wad(iwad, meta)
     t0 = time.perf_counter()
-    built = wad.build_level(args.level)
+    built = wad.build_level(args.level, gpu_tessellation=True)   # SSECTOR -> polygon, SEG -> quad kernels
     t_build = time.perf_counter() - t0
     level = rd.DeviceLevel(built)                      # level arrays now resident in HBM
     batch = rd.Batch(level, args.width, args.height, args.poses)

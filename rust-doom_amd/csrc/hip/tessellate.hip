@@ -1,4 +1,4 @@
-// SSECTOR -> convex floor/ceiling polygon on the device (gfx950).
+// Level tessellation on the device (gfx950): SSECTOR -> convex floor/ceiling polygon, SEG -> wall quads.
 //
 // Restates LevelWalker::subsector's implicit-point search and points_to_polygon
 // (wad/src/visitor.rs:672-699, 1184-1259; math/src/line.rs:43-84) as one wavefront per sub-sector:
@@ -150,6 +150,155 @@ __global__ __launch_bounds__(64) void subsector_polygon_kernel(const LeafDesc *_
   out_n[blockIdx.x] = out_count;
 }
 
+// =================================================================================================
+// SEG -> wall quads (+ sky quads).  One lane per seg restates LevelWalker::seg (visitor.rs:711-837: which
+// of lower / upper / middle / one-sided wall and sky quads exist, their height spans, pegging and owner
+// object), wall_quad (visitor.rs:839-937: end points pushed outward by POLY_BIAS along the wall, heights
+// / 100 +- POLY_BIAS, s from seg offset + biased length * 100, t by pegging + y offset, fake contrast,
+// scroll) and sky_quad (visitor.rs:987-1008).  Every table lookup (sectors, sidedefs, texture heights,
+// dynamic-sector ranges) was resolved into SegInput by the host; the arithmetic is here.  binary32, no
+// contraction: bit-identical to the host walk (tests/test_gpu_tessellate.py).
+// =================================================================================================
+using rdoom::wad::SegGeometry;
+using rdoom::wad::SegInput;
+using rdoom::wad::SegQuadGeometry;
+using rdoom::wad::SegSkyGeometry;
+
+enum SegPeg { PEG_TOP, PEG_BOTTOM, PEG_BOTTOM_LOWER, PEG_TOP_FLOAT, PEG_BOTTOM_FLOAT };
+
+__device__ __forceinline__ float from_wad_height_d(int16_t x) { return (float)x / 100.0f; }
+
+__device__ void seg_wall_quad(const SegInput &in, SegQuadGeometry &out, uint32_t object_id, int16_t low_i, int16_t high_i,
+                              int slot, SegPeg peg, bool blocker) {
+  out.valid = 0;
+  if (low_i >= high_i) return;
+  const int16_t th = in.tex_h[slot];
+  if (th == -2) return;  // "No such wall texture": the quad is skipped
+  const bool textured = th >= 0;
+  float dx = in.v2x - in.v1x, dy = in.v2y - in.v1y;
+  float m = mag(dx, dy);
+  if (!(m > kEps)) m = kEps;  // normalize_or_zero
+  dx = dx / m;
+  dy = dy / m;
+  const float bx = dx * kPolyBias, by = dy * kPolyBias;
+  const float v1x = in.v1x + (-bx), v1y = in.v1y + (-by), v2x = in.v2x + bx, v2y = in.v2y + by;
+  float low, high;
+  if (textured && peg == PEG_TOP_FLOAT) {
+    low = from_wad_height_d((int16_t)(low_i + in.y_offset));
+    high = from_wad_height_d((int16_t)(low_i + th + in.y_offset));
+  } else if (textured && peg == PEG_BOTTOM_FLOAT) {
+    low = from_wad_height_d((int16_t)(high_i + in.y_offset - th));
+    high = from_wad_height_d((int16_t)(high_i + in.y_offset));
+  } else {
+    low = from_wad_height_d(low_i);
+    high = from_wad_height_d(high_i);
+  }
+  uint32_t contrast = 0;
+  if (!(in.flags & rdoom::wad::SEG_LIGHT_EFFECT)) {
+    if (fabsf(v1x - v2x) < kEps)
+      contrast = 1;
+    else if (fabsf(v1y - v2y) < kEps)
+      contrast = 2;
+  }
+  const float height = (high - low) * 100.0f;
+  const float s1 = (float)in.seg_offset + (float)in.x_offset;
+  const float s2 = s1 + mag(v2x - v1x, v2y - v1y) * 100.0f;
+  const float fth = (float)th;
+  float t1, t2;
+  if (!textured || peg == PEG_TOP) {
+    t1 = height;
+    t2 = 0.0f;
+  } else if (peg == PEG_BOTTOM) {
+    t1 = fth;
+    t2 = fth - height;
+  } else if (peg == PEG_BOTTOM_LOWER) {
+    const float sector_height = (float)(int16_t)(in.ceiling - in.floor);
+    t1 = fth + sector_height;
+    t2 = fth - height + sector_height;
+  } else {
+    t1 = fth;
+    t2 = 0.0f;
+  }
+  t1 = t1 + (float)in.y_offset;
+  t2 = t2 + (float)in.y_offset;
+  out.valid = 1;
+  out.object_id = object_id;
+  out.v1x = v1x, out.v1y = v1y, out.v2x = v2x, out.v2y = v2y;
+  out.s1 = s1, out.t1 = t1, out.s2 = s2, out.t2 = t2;
+  out.low = low - kPolyBias;
+  out.high = high + kPolyBias;
+  out.scroll = (in.flags & rdoom::wad::SEG_SCROLL) ? 35.0f : 0.0f;
+  out.contrast = contrast;
+  out.slot = (uint32_t)slot;
+  out.blocker = blocker ? 1u : 0u;
+}
+
+__device__ void seg_sky_quad(const SegInput &in, SegSkyGeometry &out, uint32_t object_id, int16_t low, int16_t high) {
+  out.valid = 0;
+  if (low >= high) return;
+  float ex = in.v2x - in.v1x, ey = in.v2y - in.v1y;
+  float m = mag(ex, ey);
+  if (!(m > kEps)) m = kEps;
+  ex = ex / m;
+  ey = ey / m;
+  const float bx = ex * kPolyBias * 16.0f, by = ey * kPolyBias * 16.0f;
+  const float nx = -ey, ny = ex;
+  const float nbx = nx * kPolyBias * 16.0f, nby = ny * kPolyBias * 16.0f;
+  out.valid = 1;
+  out.object_id = object_id;
+  out.v1x = in.v1x + (nbx - bx), out.v1y = in.v1y + (nby - by);
+  out.v2x = in.v2x + (nbx + bx), out.v2y = in.v2y + (nby + by);
+  out.low = from_wad_height_d(low);
+  out.high = from_wad_height_d(high);
+}
+
+__global__ __launch_bounds__(64) void seg_quads_kernel(const SegInput *__restrict__ inputs, SegGeometry *__restrict__ outputs,
+                                                       uint32_t n) {
+  using namespace rdoom::wad;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const SegInput in = inputs[i];
+  SegGeometry g;
+  for (int k = 0; k < 3; k++) g.quad[k].valid = 0;
+  g.sky[0].valid = g.sky[1].valid = 0;
+  if (in.flags & SEG_VALID) {
+    const bool unpeg_lower = (in.flags & SEG_UNPEG_LOWER) != 0, unpeg_upper = (in.flags & SEG_UNPEG_UPPER) != 0;
+    const int16_t max_height = (int16_t)(in.f_ceil_hi - in.f_floor_lo);  // SectorInfo::max_height
+    if (!(in.flags & SEG_HAS_BACK)) {
+      seg_wall_quad(in, g.quad[0], unpeg_lower ? in.f_floor_id : in.f_ceil_id,
+                    unpeg_lower ? in.floor : (int16_t)(in.ceiling - max_height),
+                    unpeg_lower ? (int16_t)(in.floor + max_height) : in.ceiling, 2, unpeg_lower ? PEG_BOTTOM : PEG_TOP, true);
+      if (in.flags & SEG_F_CEIL_SKY) seg_sky_quad(in, g.sky[0], in.f_ceil_id, in.ceiling, in.mx);
+      if (in.flags & SEG_F_FLOOR_SKY) seg_sky_quad(in, g.sky[1], in.f_floor_id, in.mn, in.floor);
+    } else {
+      if ((in.flags & SEG_F_CEIL_SKY) && !(in.flags & SEG_B_CEIL_SKY)) seg_sky_quad(in, g.sky[0], in.f_ceil_id, in.ceiling, in.mx);
+      if ((in.flags & SEG_F_FLOOR_SKY) && !(in.flags & SEG_B_FLOOR_SKY)) seg_sky_quad(in, g.sky[1], in.f_floor_id, in.mn, in.floor);
+      int16_t fl, ce;
+      if (in.b_floor_hi > in.f_floor_lo) {
+        seg_wall_quad(in, g.quad[0], in.b_floor_id, (int16_t)(in.back_floor - in.b_floor_hi + in.f_floor_lo), in.back_floor, 0,
+                      unpeg_lower ? PEG_BOTTOM_LOWER : PEG_TOP, true);
+        fl = in.back_floor;
+      } else {
+        fl = in.floor;
+      }
+      if (in.back_ceiling < in.ceiling) {
+        if (!(in.flags & SEG_B_CEIL_SKY))
+          seg_wall_quad(in, g.quad[1], in.b_ceil_id, in.back_ceiling, in.ceiling, 1, unpeg_upper ? PEG_TOP : PEG_BOTTOM, true);
+        ce = in.back_ceiling;
+      } else {
+        ce = in.ceiling;
+      }
+      SegPeg peg;
+      if (unpeg_lower)
+        peg = in.tex_h[1] == -1 ? PEG_TOP_FLOAT : PEG_BOTTOM;
+      else
+        peg = in.tex_h[0] == -1 ? PEG_BOTTOM_FLOAT : PEG_TOP;
+      seg_wall_quad(in, g.quad[2], unpeg_lower ? in.f_floor_id : in.f_ceil_id, fl, ce, 2, peg, (in.flags & SEG_IMPASSABLE) != 0);
+    }
+  }
+  outputs[i] = g;
+}
+
 struct DevBuf {
   void *p = nullptr;
   ~DevBuf() {
@@ -224,6 +373,24 @@ std::vector<std::vector<wad::Pnt2f>> tessellate_on_device(const wad::Level &leve
     for (uint32_t k = 0; k < counts[i]; k++) poly.push_back({out[i * MAX_POINTS + k].x, out[i * MAX_POINTS + k].y});
   }
   return polygons;
+}
+
+// SEG -> wall quads on the device: one lane per recorded seg (see seg_quads_kernel)
+std::vector<wad::SegGeometry> tessellate_segs_on_device(const std::vector<wad::SegInput> &inputs) {
+  using wad::WadError;
+  std::vector<wad::SegGeometry> out(inputs.size());
+  if (inputs.empty()) return out;
+  DevBuf d_in, d_out;
+  hipError_t e = d_in.alloc_copy(inputs.data(), inputs.size() * sizeof(wad::SegInput));
+  if (e == hipSuccess) e = d_out.alloc_copy(nullptr, out.size() * sizeof(wad::SegGeometry));
+  if (e != hipSuccess) throw WadError(RDOOM_HIP_ERROR, std::string("tessellate segs: ") + hipGetErrorString(e));
+  const uint32_t n = (uint32_t)inputs.size();
+  hipLaunchKernelGGL(seg_quads_kernel, dim3((n + 63u) / 64u), dim3(64), 0, 0, (const wad::SegInput *)d_in.p,
+                     (wad::SegGeometry *)d_out.p, n);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(out.data(), d_out.p, out.size() * sizeof(wad::SegGeometry), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) throw WadError(RDOOM_HIP_ERROR, std::string("tessellate segs: ") + hipGetErrorString(e));
+  return out;
 }
 
 }  // namespace rdoom::game

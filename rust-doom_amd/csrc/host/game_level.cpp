@@ -170,7 +170,8 @@ void Builder::visit_decor(const Decor &d) {  // level.rs:764-793
 }
 
 // ---- level assembly -------------------------------------------------------------------------------------
-std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, TessellateFn tessellate) {
+std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, TessellateFn tessellate,
+                                        TessellateSegsFn tessellate_segs) {
   const Archive &archive = *w.archive;
   const TextureDirectory &tex = w.textures;
   const Level level = Level::from_archive(archive, level_index);
@@ -226,19 +227,26 @@ std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, 
   Builder builder(materials);
   LevelWalker walker(level, analysis, tex, archive.metadata(), builder);
   std::vector<std::vector<Pnt2f>> polygons;
+  std::vector<wad::SegGeometry> seg_geometry;
   if (tessellate) {
-    // leaf inputs come from a visitor-free pre-walk; polygons from the device
+    // leaf inputs (and per-seg inputs) come from a visitor-free pre-walk; polygons and wall quads from the device
     std::vector<LevelWalker::LeafInput> leaves;
+    std::vector<wad::SegInput> seg_inputs(level.segs.size());  // flags == 0: seg never visited / skipped
     {
       LevelVisitor nothing;
       LevelWalker pre(level, analysis, tex, archive.metadata(), nothing);
       pre.record_leaves = &leaves;
+      if (tessellate_segs) pre.record_segs = &seg_inputs;
       std::vector<std::vector<Pnt2f>> empty(level.subsectors.size());
       pre.precomputed_polygons = &empty;
       pre.walk();
     }
     polygons = tessellate(level, leaves);
     walker.precomputed_polygons = &polygons;
+    if (tessellate_segs) {
+      seg_geometry = tessellate_segs(seg_inputs);
+      walker.precomputed_segs = &seg_geometry;
+    }
   }
   walker.walk();
 

@@ -89,6 +89,10 @@ struct LoadedWad {
 // sub-sector polygons computed on the GPU (indexed by sub-sector id).
 using TessellateFn = std::vector<std::vector<wad::Pnt2f>> (*)(const wad::Level &,
                                                               const std::vector<wad::LevelWalker::LeafInput> &);
-std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, TessellateFn tessellate);
+// `tessellate_segs` (optional, with `tessellate`): called with the recorded per-seg inputs, returns the wall / sky
+// quad geometry computed on the GPU (indexed by seg).
+using TessellateSegsFn = std::vector<wad::SegGeometry> (*)(const std::vector<wad::SegInput> &);
+std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, TessellateFn tessellate,
+                                        TessellateSegsFn tessellate_segs = nullptr);
 
 }  // namespace rdoom::game

@@ -441,6 +441,42 @@ struct SectorInfo {  // visitor.rs:145-156
   int16_t max_height() const { return (int16_t)(ceiling_range.second - floor_range.first); }
 };
 
+// ---- SEG -> wall quads on the device (csrc/hip/tessellate.hip) --------------------------------------
+// SegInput: everything LevelWalker::seg + wall_quad + sky_quad (visitor.rs:711-937, 987-1008) read for one seg,
+// with every table lookup resolved on the host.  SegGeometry: the quads they emit, in emission order.
+// Plain data shared by the host walk and the HIP kernel.
+struct SegInput {
+  float v1x, v1y, v2x, v2y;                      // seg end points, world units (from_wad_coords)
+  int16_t floor, ceiling, back_floor, back_ceiling;
+  int16_t f_floor_lo, f_floor_hi, f_ceil_lo, f_ceil_hi;  // SectorInfo ranges of the sub-sector's sector
+  int16_t b_floor_lo, b_floor_hi, b_ceil_lo, b_ceil_hi;  // ... of the back sector
+  int16_t mn, mx;                                // level height range (visitor.rs:1173-1182)
+  int16_t x_offset, y_offset;                    // sidedef offsets
+  uint16_t seg_offset;
+  int16_t tex_h[3];                              // texture height of lower, upper, middle; -1 untextured, -2 unknown texture
+  uint16_t sector_height_pad;
+  uint32_t flags;                                // SEG_* bits
+  uint32_t f_floor_id, f_ceil_id, b_floor_id, b_ceil_id;
+};
+constexpr uint32_t SEG_VALID = 1u, SEG_HAS_BACK = 2u, SEG_UNPEG_LOWER = 4u, SEG_UNPEG_UPPER = 8u, SEG_IMPASSABLE = 16u,
+                   SEG_SCROLL = 32u, SEG_F_CEIL_SKY = 64u, SEG_F_FLOOR_SKY = 128u, SEG_B_CEIL_SKY = 256u,
+                   SEG_B_FLOOR_SKY = 512u, SEG_LIGHT_EFFECT = 1024u;
+struct SegQuadGeometry {  // one StaticQuad minus the host-side references (light, texture name)
+  uint32_t valid, object_id;
+  float v1x, v1y, v2x, v2y, s1, t1, s2, t2, low, high, scroll;
+  uint32_t contrast;  // 0 none, 1 brighten, 2 darken (visitor.rs:889-901)
+  uint32_t slot;      // 0 lower, 1 upper, 2 middle texture of the sidedef
+  uint32_t blocker;
+};
+struct SegSkyGeometry {
+  uint32_t valid, object_id;
+  float v1x, v1y, v2x, v2y, low, high;
+};
+struct SegGeometry {
+  SegQuadGeometry quad[3];  // one-sided: [0] = the wall; two-sided: lower, upper, middle
+  SegSkyGeometry sky[2];    // ceiling side, floor side
+};
+
 // points_to_polygon (visitor.rs:1192-1259); exposed because the GPU tessellation kernel restates it.
 void points_to_polygon(std::vector<Pnt2f> &points);
 Line2f partition_line(const WadNode &node);  // visitor.rs:1150-1155
@@ -460,6 +496,11 @@ class LevelWalker {  // visitor.rs:499-1138
     std::vector<Line2f> bsp_lines;
   };
   std::vector<LeafInput> *record_leaves = nullptr;
+  // Same for the SEG -> wall-quad half: record_segs (sized level.segs.size()) collects the per-seg inputs
+  // instead of emitting quads; precomputed_segs (same indexing) replaces the host arithmetic of seg() /
+  // wall_quad() / sky_quad() by the device's results.
+  std::vector<SegInput> *record_segs = nullptr;
+  const std::vector<SegGeometry> *precomputed_segs = nullptr;
 
  private:
   const Level &level_;
@@ -490,6 +531,8 @@ class LevelWalker {  // visitor.rs:499-1138
     bool blocker;
   };
   void seg(const WadSector *sector, const SectorInfo &info, const WadSeg &seg, Pnt2f v1, Pnt2f v2);
+  bool seg_input(const WadSector *sector, const SectorInfo &info, const WadSeg &seg, Pnt2f v1, Pnt2f v2, SegInput &out);
+  void emit_seg_geometry(const WadSector *sector, const WadSeg &seg, const SegGeometry &g);
   void wall_quad(const InternalWallQuad &q);
   void flat_poly(const WadSector *sector, const SectorInfo &info);
   void sky_quad(ObjectId id, Pnt2f v1, Pnt2f v2, int16_t low, int16_t high);

@@ -7,6 +7,8 @@ namespace rdoom::game {
 // defined in csrc/hip/tessellate.hip: SSECTOR -> convex polygon on the device
 std::vector<std::vector<wad::Pnt2f>> tessellate_on_device(const wad::Level &level,
                                                           const std::vector<wad::LevelWalker::LeafInput> &leaves);
+// SEG -> wall / sky quads on the device
+std::vector<wad::SegGeometry> tessellate_segs_on_device(const std::vector<wad::SegInput> &inputs);
 }  // namespace rdoom::game
 
 struct rdoom_wad {
@@ -79,7 +81,8 @@ rdoom_status rdoom_wad_build_level(const rdoom_wad *wad, uint32_t level_index, i
   return guarded([&]() -> rdoom_status {
     auto b = std::make_unique<rdoom_built>();
     b->b = rdoom::game::build_level(wad->w, level_index,
-                                    use_gpu_tessellation ? &rdoom::game::tessellate_on_device : nullptr);
+                                    use_gpu_tessellation ? &rdoom::game::tessellate_on_device : nullptr,
+                                    use_gpu_tessellation ? &rdoom::game::tessellate_segs_on_device : nullptr);
     *out_built = b.release();
     return RDOOM_OK;
   });

@@ -335,6 +335,16 @@ void LevelWalker::subsector(size_t id) {  // visitor.rs:621-709
 
 void LevelWalker::seg(const WadSector *sector, const SectorInfo &info, const WadSeg &sg, Pnt2f v1,
                       Pnt2f v2) {  // visitor.rs:711-837
+  if (record_segs || precomputed_segs) {
+    const size_t index = (size_t)(&sg - level_.segs.data());
+    if (record_segs) {
+      SegInput in{};
+      if (seg_input(sector, info, sg, v1, v2, in)) (*record_segs)[index] = in;
+      return;
+    }
+    emit_seg_geometry(sector, sg, (*precomputed_segs)[index]);
+    return;
+  }
   const WadLinedef *line = level_.seg_linedef(sg);
   if (!line) return;
   const WadSidedef *sidedef = level_.seg_sidedef(sg);
@@ -390,6 +400,99 @@ void LevelWalker::seg(const WadSector *sector, const SectorInfo &info, const Wad
     peg = sidedef->lower_texture.is_untextured() ? Peg::BottomFloat : Peg::Top;
   wall_quad({unpeg_lower ? info.floor_id : info.ceiling_id, sector, &sg, v1, v2, fl, ce, sidedef->middle_texture, peg,
              line->impassable()});
+}
+
+// Inputs of the device SEG kernel: every lookup seg() / wall_quad() / sky_quad() perform, resolved.
+bool LevelWalker::seg_input(const WadSector *sector, const SectorInfo &info, const WadSeg &sg, Pnt2f v1, Pnt2f v2,
+                            SegInput &in) {
+  const WadLinedef *line = level_.seg_linedef(sg);
+  const WadSidedef *sidedef = level_.seg_sidedef(sg);
+  if (!line || !sidedef) return false;
+  in.v1x = v1.x, in.v1y = v1.y, in.v2x = v2.x, in.v2y = v2.y;
+  in.floor = sector->floor_height, in.ceiling = sector->ceiling_height;
+  in.f_floor_lo = info.floor_range.first, in.f_floor_hi = info.floor_range.second;
+  in.f_ceil_lo = info.ceiling_range.first, in.f_ceil_hi = info.ceiling_range.second;
+  in.mn = height_range_.first, in.mx = height_range_.second;
+  in.x_offset = sidedef->x_offset, in.y_offset = sidedef->y_offset;
+  in.seg_offset = sg.offset;
+  const WadName names[3] = {sidedef->lower_texture, sidedef->upper_texture, sidedef->middle_texture};
+  for (int k = 0; k < 3; k++) {
+    if (names[k].is_untextured()) {
+      in.tex_h[k] = -1;
+    } else {
+      const Image *image = tex_.texture(names[k]);
+      in.tex_h[k] = image ? (int16_t)image->height() : (int16_t)-2;
+    }
+  }
+  in.f_floor_id = info.floor_id.v, in.f_ceil_id = info.ceiling_id.v;
+  uint32_t flags = SEG_VALID;
+  if (line->lower_unpegged()) flags |= SEG_UNPEG_LOWER;
+  if (line->upper_unpegged()) flags |= SEG_UNPEG_UPPER;
+  if (line->impassable()) flags |= SEG_IMPASSABLE;
+  if (line->special_type == 0x30) flags |= SEG_SCROLL;
+  if (sector->ceiling_texture.is_sky_flat()) flags |= SEG_F_CEIL_SKY;
+  if (sector->floor_texture.is_sky_flat()) flags |= SEG_F_FLOOR_SKY;
+  if (light_info(sector)->effect) flags |= SEG_LIGHT_EFFECT;
+  if (const WadSector *back = level_.seg_back_sector(sg)) {
+    flags |= SEG_HAS_BACK;
+    const SectorInfo bi = sector_info(back);
+    in.back_floor = back->floor_height, in.back_ceiling = back->ceiling_height;
+    in.b_floor_lo = bi.floor_range.first, in.b_floor_hi = bi.floor_range.second;
+    in.b_ceil_lo = bi.ceiling_range.first, in.b_ceil_hi = bi.ceiling_range.second;
+    in.b_floor_id = bi.floor_id.v, in.b_ceil_id = bi.ceiling_id.v;
+    if (back->ceiling_texture.is_sky_flat()) flags |= SEG_B_CEIL_SKY;
+    if (back->floor_texture.is_sky_flat()) flags |= SEG_B_FLOOR_SKY;
+  }
+  in.flags = flags;
+  return true;
+}
+
+// Visitor events from the device's results, in the order seg() emits them (visitor.rs:711-837).
+void LevelWalker::emit_seg_geometry(const WadSector *sector, const WadSeg &sg, const SegGeometry &g) {
+  const WadSidedef *sidedef = level_.seg_sidedef(sg);
+  if (!sidedef) return;
+  const WadName names[3] = {sidedef->lower_texture, sidedef->upper_texture, sidedef->middle_texture};
+  auto quad = [&](const SegQuadGeometry &q) {
+    if (!q.valid) return;
+    const LightInfo *light = light_info(sector);
+    LightInfo contrasted;
+    if (q.contrast) {
+      contrasted = with_contrast(*light, q.contrast == 1 ? Contrast::Brighten : Contrast::Darken);
+      light = &contrasted;
+    }
+    StaticQuad out;
+    out.object_id = ObjectId{q.object_id};
+    out.v1 = {q.v1x, q.v1y};
+    out.v2 = {q.v2x, q.v2y};
+    out.tex_start[0] = q.s1, out.tex_start[1] = q.t1;
+    out.tex_end[0] = q.s2, out.tex_end[1] = q.t2;
+    out.height_range[0] = q.low, out.height_range[1] = q.high;
+    out.light_info = light;
+    out.scroll = q.scroll;
+    if (!names[q.slot].is_untextured()) out.tex_name = names[q.slot];
+    out.blocker = q.blocker != 0;
+    visitor_.visit_wall_quad(out);
+  };
+  auto sky = [&](const SegSkyGeometry &k) {
+    if (!k.valid) return;
+    SkyQuad q;
+    q.object_id = ObjectId{k.object_id};
+    q.v1 = {k.v1x, k.v1y};
+    q.v2 = {k.v2x, k.v2y};
+    q.height_range[0] = k.low, q.height_range[1] = k.high;
+    visitor_.visit_sky_quad(q);
+  };
+  if (!level_.seg_back_sector(sg)) {  // one-sided: wall, then sky above / below
+    quad(g.quad[0]);
+    sky(g.sky[0]);
+    sky(g.sky[1]);
+  } else {  // two-sided: sky, then lower, upper, middle
+    sky(g.sky[0]);
+    sky(g.sky[1]);
+    quad(g.quad[0]);
+    quad(g.quad[1]);
+    quad(g.quad[2]);
+  }
 }
 
 void LevelWalker::wall_quad(const InternalWallQuad &q) {  // visitor.rs:839-937

@@ -1,4 +1,5 @@
-"""GPU: SSECTOR -> polygon tessellation kernel == host walk, byte for byte; product path end to end."""
+"""GPU: the tessellation kernels (SSECTOR -> convex polygon, SEG -> wall / sky quads) == the host walk, byte for
+byte on every array of every level; product path end to end."""
 import numpy as np
 import pytest
 
@@ -8,7 +9,7 @@ from util import META_PATH
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('index', [0, 1, 5, 7])
+@pytest.mark.parametrize('index', range(9))
 def test_device_tessellation_matches_host(wad_path, index):
     wad = rd.Wad(wad_path, META_PATH)
     host = wad.build_level(index, gpu_tessellation=False).arrays()
