@@ -161,6 +161,16 @@ rdoom_status rdoom_batch_render(rdoom_batch *batch, const rdoom_pose *poses, con
 rdoom_status rdoom_batch_render_timed(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
                                       uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
                                       rdoom_timings *out);
+/* Same with moving objects (doors, lifts): the reference sets u_modelview = view o model transform for the draws
+ * of each object (engine/src/renderer.rs:120-132; game/src/level.rs:203-255 moves the transforms).
+ * object_modelviews: n_poses x n_objects column-major matrices, entry [p][o] = the u_modelview of object o's draws
+ * in frame p (object 0 = the static world; an object at rest has the pose's own modelview).
+ * n_objects >= rdoom_level_num_objects. */
+rdoom_status rdoom_batch_render_objects(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                        uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
+                                        const float *object_modelviews, uint32_t n_objects);
+/* 1 + the largest rdoom_draw.object_id of the level */
+rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out);
 /* device pointer to the n_poses*height*width palette-index framebuffers of the last render */
 rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **out_device_ptr);
 /* glReadPixels analogue: synchronises, copies frames [first, first+count) to host memory */

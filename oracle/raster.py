@@ -43,6 +43,7 @@ def _load():
         except OSError:
             _lib = ctypes.CDLL(build(force=True))
         _lib.oracle_render.restype = ctypes.c_int
+        _lib.oracle_render_objects.restype = ctypes.c_int
         _lib.oracle_render_batch.restype = ctypes.c_int
     return _lib
 
@@ -76,18 +77,23 @@ class RasterOracle:
                             k['da'].shape[1] if k['da'].ndim == 2 and k['da'].size else 0,
                             k['da'].shape[0] if k['da'].ndim == 2 and k['da'].size else 0)
 
-    def render(self, modelview, projection, time, lights, width, height, kinds=ALL_KINDS, want_prim=False):
+    def render(self, modelview, projection, time, lights, width, height, kinds=ALL_KINDS, want_prim=False,
+               object_modelviews=None):
+        """object_modelviews: optional (n_objects, 16) u_modelview per object (renderer.rs:120-132)."""
         lib = _load()
         mv = np.ascontiguousarray(modelview, np.float32).reshape(16)
         pr = np.ascontiguousarray(projection, np.float32).reshape(16)
         li = np.ascontiguousarray(lights, np.uint8).reshape(256)
         fb = np.zeros((height, width), np.uint8)
         prim = np.zeros((height, width), np.uint32) if want_prim else None
-        rc = lib.oracle_render(ctypes.byref(self.level), mv.ctypes.data_as(ctypes.c_void_p),
-                               pr.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(float(time)),
-                               li.ctypes.data_as(ctypes.c_void_p), int(width), int(height), ctypes.c_uint32(kinds),
-                               fb.ctypes.data_as(ctypes.c_void_p),
-                               prim.ctypes.data_as(ctypes.c_void_p) if want_prim else None)
+        om = None if object_modelviews is None else np.ascontiguousarray(object_modelviews, np.float32).reshape(-1, 16)
+        rc = lib.oracle_render_objects(ctypes.byref(self.level), mv.ctypes.data_as(ctypes.c_void_p),
+                                       pr.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(float(time)),
+                                       li.ctypes.data_as(ctypes.c_void_p), int(width), int(height), ctypes.c_uint32(kinds),
+                                       fb.ctypes.data_as(ctypes.c_void_p),
+                                       prim.ctypes.data_as(ctypes.c_void_p) if want_prim else None,
+                                       om.ctypes.data_as(ctypes.c_void_p) if om is not None else None,
+                                       ctypes.c_uint32(0 if om is None else len(om)))
         if rc:
             raise MemoryError('oracle_render failed')
         return (fb, prim) if want_prim else fb

@@ -277,25 +277,30 @@ static uint8_t shade_sky(const OracleLevel *L, float px, float py, int width, in
 
 /* Renders one pose.  out_fb: height*width bytes, row 0 = bottom (glReadPixels order).
  * out_prim (optional): winning primitive id per pixel or NO_PRIM.  kinds_mask: bit k enables KIND k. */
+/* object_modelviews (optional): n_objects matrices, the u_modelview the reference sets for the draws of each
+ * object = view o model transform (engine/src/renderer.rs:120-132; doors / lifts move their object's transform,
+ * game/src/level.rs:203-255).  NULL = every object at identity: u_modelview = modelview for all draws. */
 static int render_with_scratch(const OracleLevel *L, const float *modelview, const float *projection, float time,
                                const uint8_t *lights, int width, int height, uint32_t kinds_mask, uint8_t *out_fb,
-                               uint32_t *out_prim, uint32_t *depth, uint32_t *prim) {
+                               uint32_t *out_prim, uint32_t *depth, uint32_t *prim, const float *object_modelviews,
+                               uint32_t n_objects) {
   size_t npx = (size_t)width * (size_t)height;
   for (size_t i = 0; i < npx; i++) {
     depth[i] = 0xFFFFFFFFu;
     prim[i] = NO_PRIM;
   }
   memset(out_fb, 0, npx);
-  float pm[16];
-  mat_mul(projection, modelview, pm);
-  /* sky.vert:10-12 */
-  float vr[2];
-  vr[0] = atan2f(pm[8], pm[10]);
-  vr[1] = pm[9] / pm[11];
   uint32_t prim_id = 0;
   for (uint32_t d = 0; d < L->n_draws; d++) {
     const Draw *dr = &L->draws[d];
     uint32_t ntri = dr->index_count / 3;
+    if (object_modelviews && dr->object_id < n_objects) modelview = object_modelviews + 16 * (size_t)dr->object_id;
+    float pm[16];
+    mat_mul(projection, modelview, pm);
+    /* sky.vert:10-12 */
+    float vr[2];
+    vr[0] = atan2f(pm[8], pm[10]);
+    vr[1] = pm[9] / pm[11];
     if (!((kinds_mask >> dr->kind) & 1u) || dr->kind > KIND_SKY) {
       prim_id += ntri;
       continue;
@@ -382,7 +387,22 @@ int oracle_render(const OracleLevel *L, const float *modelview, const float *pro
   int rc = -1;
   if (depth && prim)
     rc = render_with_scratch(L, modelview, projection, time, lights, width, height, kinds_mask, out_fb, out_prim, depth,
-                             prim);
+                             prim, 0, 0);
+  free(depth);
+  free(prim);
+  return rc;
+}
+
+int oracle_render_objects(const OracleLevel *L, const float *modelview, const float *projection, float time,
+                          const uint8_t *lights, int width, int height, uint32_t kinds_mask, uint8_t *out_fb,
+                          uint32_t *out_prim, const float *object_modelviews, uint32_t n_objects) {
+  size_t npx = (size_t)width * (size_t)height;
+  uint32_t *depth = (uint32_t *)malloc(npx * sizeof(uint32_t));
+  uint32_t *prim = (uint32_t *)malloc(npx * sizeof(uint32_t));
+  int rc = -1;
+  if (depth && prim)
+    rc = render_with_scratch(L, modelview, projection, time, lights, width, height, kinds_mask, out_fb, out_prim, depth,
+                             prim, object_modelviews, n_objects);
   free(depth);
   free(prim);
   return rc;
@@ -399,7 +419,7 @@ int oracle_render_batch(const OracleLevel *L, const float *poses, const uint8_t 
   for (int i = 0; i < n && !rc; i++) {
     const float *p = poses + (size_t)i * 33;
     rc = render_with_scratch(L, p, p + 16, p[32], lights + (size_t)i * 256, width, height, kinds_mask,
-                             out_fb + (size_t)i * npx, 0, depth, prim);
+                             out_fb + (size_t)i * npx, 0, depth, prim, 0, 0);
   }
   free(depth);
   free(prim);

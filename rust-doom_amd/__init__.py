@@ -76,7 +76,7 @@ API_SYMBOLS = [
     'rdoom_wad_open', 'rdoom_wad_close', 'rdoom_wad_num_levels', 'rdoom_wad_level_name',
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
     'rdoom_built_counters', 'rdoom_built_lights_at', 'rdoom_built_start', 'rdoom_built_floor_centroids',
-    'rdoom_pose_look', 'rdoom_selftest_fastmath']
+    'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_batch_render_objects', 'rdoom_level_num_objects']
 
 _lib = None
 
@@ -290,6 +290,11 @@ class DeviceLevel:
         self._h = ctypes.c_void_p()
         _check(lib().rdoom_level_create(ctypes.byref(desc), ctypes.byref(self._h)))
 
+    def num_objects(self):
+        n = ctypes.c_uint32()
+        _check(lib().rdoom_level_num_objects(self._h, ctypes.byref(n)))
+        return n.value
+
     def close(self):
         if self._h:
             lib().rdoom_level_destroy(self._h)
@@ -325,10 +330,17 @@ class Batch:
             stride = 256
         return poses, lights, stride
 
-    def render(self, poses, lights, kinds=ALL_KINDS, stream=None, timed=False):
-        """rdoom_batch_render(_timed): asynchronous unless timed; returns Timings fields when timed."""
+    def render(self, poses, lights, kinds=ALL_KINDS, stream=None, timed=False, object_modelviews=None):
+        """rdoom_batch_render(_timed): asynchronous unless timed; returns Timings fields when timed.
+        object_modelviews: optional (n_poses, n_objects, 16) u_modelview per object -> rdoom_batch_render_objects."""
         poses, lights, stride = self._prep(poses, lights)
         self.last_n = len(poses)
+        if object_modelviews is not None:
+            om = np.ascontiguousarray(object_modelviews, np.float32).reshape(len(poses), -1, 16)
+            _check(lib().rdoom_batch_render_objects(
+                self._h, poses.ctypes.data_as(ctypes.c_void_p), lights.ctypes.data_as(ctypes.c_void_p), stride,
+                len(poses), int(kinds), ctypes.c_void_p(stream or 0), om.ctypes.data_as(ctypes.c_void_p), om.shape[1]))
+            return None
         args = (self._h, poses.ctypes.data_as(ctypes.c_void_p), lights.ctypes.data_as(ctypes.c_void_p), stride,
                 len(poses), int(kinds), ctypes.c_void_p(stream or 0))
         if not timed:

@@ -36,7 +36,7 @@ struct alignas(16) LevelTri {  // 96 bytes
   float uv[6];
   float scroll[3];              // a_scroll_rate per vertex; for decor triangles: a_local_x per vertex
   float atlas_u, atlas_v, size_x, size_y, row_height;
-  uint32_t packed;  // num_frames | light << 8 | kind << 16 | masked border << 18 | masked interior << 19
+  uint32_t packed;  // num_frames | light << 8 | kind << 16 | masked border << 18 | masked interior << 19 | object id << 20
 };
 static_assert(sizeof(LevelTri) == 96, "LevelTri layout");
 
@@ -47,6 +47,15 @@ struct alignas(16) PoseConst {  // 464 bytes
   float mv[16], proj[16];       // the two uniforms themselves: sprite.vert transforms in two steps (D1..D3)
 };
 static_assert(sizeof(PoseConst) == 464, "PoseConst layout");
+
+// Per (pose, object) uniforms when objects move (doors, lifts): the reference sets u_modelview = view o model
+// transform for the draws of each object (engine/src/renderer.rs:120-132, game/src/level.rs:203-255).
+struct alignas(16) ObjectConst {  // 144 bytes
+  float pm[16];                   // projection * object modelview (V1)
+  float mv[16];                   // object modelview
+  float vr0, vr1, pad0, pad1;     // sky.vert:10-12 from this object's transform
+};
+static_assert(sizeof(ObjectConst) == 144, "ObjectConst layout");
 
 // ---- per (pose, visible triangle) records -----------------------------------------------------
 struct alignas(16) RasterRec {  // 80 bytes
@@ -120,7 +129,8 @@ __device__ __forceinline__ float glsl_mod(float x, float y) { return x - y * flo
 constexpr uint32_t SORT_BUCKETS = 2048;
 constexpr uint32_t SORT_KEY_CAP = 24576;  // triangles per pose whose keys fit the LDS key array
 
-__device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const PoseConst &pc, uint32_t t, int width,
+__device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const PoseConst &pc,
+                                               const ObjectConst *__restrict__ objs, uint32_t t, int width,
                                                int height, uint32_t kinds_mask, RasterRec &rr, ShadeRec &sr,
                                                float &wkey) {
   wkey = 0.0f;
@@ -130,6 +140,13 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
     const uint32_t kind = (tri.packed >> 16) & 3u;
     ok = ((kinds_mask >> kind) & 1u) != 0u;
     if (ok) {
+      // uniforms of this triangle's object: the pose's own unless objects move
+      const float *pm = pc.pm, *mv = pc.mv;
+      float vr0 = pc.vr0, vr1 = pc.vr1;
+      if (objs) {
+        const ObjectConst &oc = objs[tri.packed >> 20];
+        pm = oc.pm, mv = oc.mv, vr0 = oc.vr0, vr1 = oc.vr1;
+      }
       float clip[3][4], u[3], v[3];
 #pragma unroll
       for (int i = 0; i < 3; i++) {
@@ -138,10 +155,10 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
           // D1..D3 (sprite.vert:41-46): camera-facing expansion along row 0 of the modelview, then
           // projection * (modelview * pos) in two steps
           const float lx = tri.scroll[i];
-          const float px = fmaf(pc.mv[0], lx, x), py = fmaf(pc.mv[4], lx, y), pz = fmaf(pc.mv[8], lx, z);
+          const float px = fmaf(mv[0], lx, x), py = fmaf(mv[4], lx, y), pz = fmaf(mv[8], lx, z);
           float eye[4];
 #pragma unroll
-          for (int r = 0; r < 4; r++) eye[r] = fmaf(pc.mv[8 + r], pz, fmaf(pc.mv[4 + r], py, fmaf(pc.mv[r], px, pc.mv[12 + r])));
+          for (int r = 0; r < 4; r++) eye[r] = fmaf(mv[8 + r], pz, fmaf(mv[4 + r], py, fmaf(mv[r], px, mv[12 + r])));
 #pragma unroll
           for (int r = 0; r < 4; r++)
             clip[i][r] = fmaf(pc.proj[12 + r], eye[3], fmaf(pc.proj[8 + r], eye[2], fmaf(pc.proj[4 + r], eye[1], pc.proj[r] * eye[0])));
@@ -149,7 +166,7 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
         } else {
 #pragma unroll
           for (int r = 0; r < 4; r++)
-            clip[i][r] = fmaf(pc.pm[8 + r], z, fmaf(pc.pm[4 + r], y, fmaf(pc.pm[r], x, pc.pm[12 + r])));
+            clip[i][r] = fmaf(pm[8 + r], z, fmaf(pm[4 + r], y, fmaf(pm[r], x, pm[12 + r])));
           u[i] = tri.uv[2 * i] + pc.time * tri.scroll[i];
         }
         v[i] = tri.uv[2 * i + 1];
@@ -157,6 +174,7 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
       // flat varyings (provoking vertex data were folded into LevelTri on the host)
       const uint32_t nframes = tri.packed & 0xFFu;
       float au = tri.atlas_u, av = tri.atlas_v;
+      if (kind == RDOOM_KIND_SKY) au = vr0, av = vr1;  // sky records carry v_r (flat varying of sky.vert) here
       if (nframes != 1u && kind != RDOOM_KIND_SKY) {
         const float aw = kind == RDOOM_KIND_FLAT ? (float)lv.flat_w : (kind == RDOOM_KIND_DECOR ? (float)lv.decor_w : (float)lv.wall_w);
         const float anim_fps = 8.0f / 35.0f;
@@ -270,6 +288,7 @@ __device__ __forceinline__ uint32_t depth_bucket(float wmin) {
 }
 
 __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
+                                                    const ObjectConst *__restrict__ objects, uint32_t n_objects,
                                                     int width, int height, uint32_t kinds_mask,
                                                     TriRec *__restrict__ recs, TriRec *__restrict__ tmp_recs,
                                                     uint4 *__restrict__ sorted, uint32_t *__restrict__ counts,
@@ -292,7 +311,8 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
     RasterRec rr;
     ShadeRec sr;
     float wkey;
-    const bool ok = t < lv.ntri && setup_triangle(lv, pc, t, width, height, kinds_mask, rr, sr, wkey);
+    const bool ok = t < lv.ntri && setup_triangle(lv, pc, objects ? objects + (size_t)pose * n_objects : nullptr, t,
+                                                  width, height, kinds_mask, rr, sr, wkey);
     const unsigned long long m = __ballot(ok);
     if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
     __syncthreads();
@@ -908,7 +928,7 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
                                                 float px, float py, float row_w, float row_u, float row_v,
                                                 int width, int height, const PoseConst &pc) {
   const uint32_t kind = s.flags & 3u;
-  if (kind == RDOOM_KIND_SKY) return shade_sky(lv, cmap, px, py, width, height, pc.vr0, pc.vr1);
+  if (kind == RDOOM_KIND_SKY) return shade_sky(lv, cmap, px, py, width, height, s.atlas_u, s.atlas_v);
   const TexelAt t = texel_coords(s, px, row_w, row_u, row_v);
   const uint32_t texel = load_texel(lv, s, t.ix, t.iy);
   if (kind != RDOOM_KIND_FLAT && (texel & 0x8000u)) return 0x100u;
@@ -1217,7 +1237,7 @@ struct rdoom_level {
   int device = 0;
   DeviceLevelView view{};
   void *d_tris = nullptr, *d_flat = nullptr, *d_wall = nullptr, *d_sky = nullptr, *d_cmap = nullptr;
-  uint32_t ntri = 0;
+  uint32_t ntri = 0, n_objects = 1;
 };
 
 struct rdoom_batch {
@@ -1237,6 +1257,7 @@ struct rdoom_batch {
   uint32_t *d_counts = nullptr, *d_vis = nullptr, *d_prim = nullptr;
   uint8_t *d_fb = nullptr;
   PoseConst *h_poses = nullptr;  // pinned staging for the per-pose constants
+  ObjectConst *d_objects = nullptr, *h_objects = nullptr;  // max_poses x n_objects, allocated on first use
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_copy = nullptr;  // H2D of h_poses finished: staging may be rewritten
   bool want_prim = false;
@@ -1279,6 +1300,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
     return rdoom::fail(RDOOM_BAD_ARG, "atlas larger than 32768 texels on a side");
   // flatten the draws into one primitive list in draw order (primitive id == position)
   std::vector<LevelTri> tris;
+  uint32_t n_objects = 1;
   // Alpha-test classification of a wall texture (all its animation frames): bit 0 = a texel in the
   // one-texel ring AROUND the rectangle is transparent (the float mod of F2 can land there), bit 1 =
   // the rectangle itself contains transparent texels (a genuinely masked texture).
@@ -1314,6 +1336,8 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
   for (uint32_t di = 0; di < d->n_draws; di++) {
     const rdoom_draw &dr = d->draws[di];
     if (dr.index_count % 3 != 0) return rdoom::fail(RDOOM_BAD_ARG, "draw %u: index_count not a multiple of 3", di);
+    if (dr.object_id >= 4096u) return rdoom::fail(RDOOM_BAD_LEVEL, "draw %u: object id %u (at most 4095)", di, dr.object_id);
+    n_objects = std::max(n_objects, dr.object_id + 1u);
     for (uint32_t t = 0; t < dr.index_count / 3; t++) {
       LevelTri lt;
       std::memset(&lt, 0, sizeof lt);
@@ -1379,6 +1403,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
       } else {
         return rdoom::fail(RDOOM_BAD_ARG, "draw %u: unknown kind %u", di, dr.kind);
       }
+      lt.packed |= dr.object_id << 20;
       tris.push_back(lt);
     }
   }
@@ -1386,6 +1411,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
   rdoom_level *lv = new rdoom_level;
   (void)hipGetDevice(&lv->device);
   lv->ntri = (uint32_t)tris.size();
+  lv->n_objects = n_objects;
   auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
     if (bytes == 0 || !src) {
       *dst = nullptr;
@@ -1448,6 +1474,8 @@ void rdoom_batch_destroy(rdoom_batch *b) {
     if (e) (void)hipEventDestroy(e);
   if (b->ev_copy) (void)hipEventDestroy(b->ev_copy);
   if (b->h_poses) (void)hipHostFree(b->h_poses);
+  if (b->h_objects) (void)hipHostFree(b->h_objects);
+  if (b->d_objects) (void)hipFree(b->d_objects);
   delete b;
 }
 
@@ -1493,20 +1521,41 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   return RDOOM_OK;
 }
 
+static void mat_mul_v1(const float *P, const float *M, float *pm) {  // V1: PM = P * M, plain multiply/add, left to right
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++)
+      pm[c * 4 + r] = ((P[0 * 4 + r] * M[c * 4 + 0] + P[1 * 4 + r] * M[c * 4 + 1]) + P[2 * 4 + r] * M[c * 4 + 2]) +
+                      P[3 * 4 + r] * M[c * 4 + 3];
+}
+
 static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const uint8_t *lights, uint32_t lights_stride,
-                                uint32_t n, uint32_t kinds_mask, hipStream_t st, rdoom_timings *tm) {
+                                uint32_t n, uint32_t kinds_mask, hipStream_t st, rdoom_timings *tm,
+                                const float *object_modelviews = nullptr, uint32_t n_objects = 0) {
   if (!b || !poses || !lights) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   if (n == 0 || n > b->max_poses) return rdoom::fail(RDOOM_BAD_ARG, "n_poses %u outside 1..%u", n, b->max_poses);
   const rdoom_level *lv = b->level;
+  if (object_modelviews && n_objects < lv->n_objects)
+    return rdoom::fail(RDOOM_BAD_ARG, "n_objects %u but the level draws objects 0..%u", n_objects, lv->n_objects - 1);
   HIP_TRY(hipEventSynchronize(b->ev_copy));  // previous render's H2D must be done before restaging
+  if (object_modelviews) {
+    const size_t count = (size_t)b->max_poses * lv->n_objects;
+    if (!b->d_objects) HIP_TRY(hipMalloc((void **)&b->d_objects, sizeof(ObjectConst) * count));
+    if (!b->h_objects) HIP_TRY(hipHostMalloc((void **)&b->h_objects, sizeof(ObjectConst) * count, hipHostMallocDefault));
+    for (uint32_t p = 0; p < n; p++)
+      for (uint32_t o = 0; o < lv->n_objects; o++) {
+        ObjectConst &oc = b->h_objects[(size_t)p * lv->n_objects + o];
+        const float *M = object_modelviews + ((size_t)p * n_objects + o) * 16;
+        mat_mul_v1(poses[p].projection, M, oc.pm);
+        std::memcpy(oc.mv, M, sizeof oc.mv);
+        oc.vr0 = atan2f(oc.pm[8], oc.pm[10]);  // sky.vert:10-12
+        oc.vr1 = oc.pm[9] / oc.pm[11];
+        oc.pad0 = oc.pad1 = 0;
+      }
+  }
   for (uint32_t p = 0; p < n; p++) {  // V1: PM = P * M, plain multiply/add, left to right
     PoseConst &pc = b->h_poses[p];
     const float *P = poses[p].projection, *M = poses[p].modelview;
-    for (int c = 0; c < 4; c++)
-      for (int r = 0; r < 4; r++)
-        pc.pm[c * 4 + r] =
-            ((P[0 * 4 + r] * M[c * 4 + 0] + P[1 * 4 + r] * M[c * 4 + 1]) + P[2 * 4 + r] * M[c * 4 + 2]) +
-            P[3 * 4 + r] * M[c * 4 + 3];
+    mat_mul_v1(P, M, pc.pm);
     std::memcpy(pc.mv, M, sizeof pc.mv);
     std::memcpy(pc.proj, P, sizeof pc.proj);
     pc.time = poses[p].time;
@@ -1518,10 +1567,15 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   b->last_n = n;
   if (tm) HIP_TRY(hipEventRecord(b->ev[0], st));
   HIP_TRY(hipMemcpyAsync(b->d_poses, b->h_poses, sizeof(PoseConst) * n, hipMemcpyHostToDevice, st));
+  if (object_modelviews)
+    HIP_TRY(hipMemcpyAsync(b->d_objects, b->h_objects, sizeof(ObjectConst) * (size_t)n * lv->n_objects,
+                           hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(b->ev_copy, st));
   const int W = (int)b->width, H = (int)b->height;
   if (lv->ntri) {
-    hipLaunchKernelGGL(setup_kernel, dim3(n), dim3(256), 0, st, lv->view, b->d_poses, W, H, kinds_mask, b->d_recs,
+    hipLaunchKernelGGL(setup_kernel, dim3(n), dim3(256), 0, st, lv->view, b->d_poses,
+                       object_modelviews ? (const ObjectConst *)b->d_objects : (const ObjectConst *)nullptr,
+                       lv->n_objects, W, H, kinds_mask, b->d_recs,
                        b->d_tmp_recs, b->d_sorted, b->d_counts, b->cap);
   }
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
@@ -1627,6 +1681,20 @@ rdoom_status rdoom_batch_render_timed(rdoom_batch *batch, const rdoom_pose *pose
                                       rdoom_timings *out) {
   if (!out) return rdoom::fail(RDOOM_BAD_ARG, "out is null");
   return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, out);
+}
+
+rdoom_status rdoom_batch_render_objects(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                        uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
+                                        const float *object_modelviews, uint32_t n_objects) {
+  if (!object_modelviews) return rdoom::fail(RDOOM_BAD_ARG, "object_modelviews is null");
+  return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, nullptr,
+                     object_modelviews, n_objects);
+}
+
+rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out) {
+  if (!level || !out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out = level->n_objects;
+  return RDOOM_OK;
 }
 
 rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **out_device_ptr) {

@@ -119,3 +119,44 @@ def test_decor_billboards(oracle_levels):
             if d[0] == rd.KIND_DECOR:
                 decor_px += int(((oprim >= first[di]) & (oprim < first[di + 1])).sum())
     assert decor_px > 10000  # the sprites really are in view
+
+
+def test_moving_objects(oracle_levels):
+    """doors / lifts move their object's transform (game/src/level.rs:203-255); the reference then
+    draws that object with u_modelview = view o model (engine/src/renderer.rs:120-132).  Every object gets its own
+    vertical offset per pose; the per-object matrices go through rdoom_batch_render_objects."""
+    lv = oracle_levels(0)
+    w, h, n = 320, 200, 10
+    n_obj = int(lv.num_objects)
+    assert n_obj > 1 and int(lv.draws[:, 1].max()) == n_obj - 1
+    poses = sweep_poses(lv, n, w, h, seed=21)
+    lights = lv.lights.fill_buffer_at(0.0)
+    rng = np.random.RandomState(5)
+    om = np.zeros((n, n_obj, 16), np.float32)
+    for p in range(n):
+        view = poses[p]['modelview'].astype(np.float64).reshape(4, 4).T  # row-major
+        for o in range(n_obj):
+            model = np.eye(4)
+            model[1, 3] = 0.0 if o == 0 else rng.uniform(-0.6, 0.6)  # object 0 is the static world
+            om[p, o] = (view @ model).T.astype(np.float32).reshape(16)
+    dev = rd.DeviceLevel(lv)
+    assert dev.num_objects() == n_obj
+    batch = rd.Batch(dev, w, h, n)
+    batch.enable_primitive_ids()
+    batch.render(poses, lights, object_modelviews=om)
+    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    ro = raster.RasterOracle(lv)
+    moved = 0
+    for i in range(n):
+        ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], 0.0, lights, w, h, want_prim=True,
+                               object_modelviews=om[i])
+        assert np.array_equal(oprim, prim[i]) and np.array_equal(ofb, fb[i]), i
+        still = ro.render(poses[i]['modelview'], poses[i]['projection'], 0.0, lights, w, h)
+        moved += int((still != ofb).sum())
+    assert moved > 2000  # the offsets are visible
+    # at rest (every object with the pose's own modelview) the image is the ordinary one
+    rest = np.repeat(poses['modelview'][:, None, :], n_obj, axis=1)
+    batch.render(poses, lights, object_modelviews=rest)
+    fb_rest = batch.read_framebuffer()
+    batch.render(poses, lights)
+    assert np.array_equal(fb_rest, batch.read_framebuffer())
