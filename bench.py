@@ -110,7 +110,7 @@ def main():
             except Exception:
                 traffic = None
         cpu = None
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             from oracle import raster
             ro = raster.RasterOracle(built.arrays())
             cores = os.cpu_count() or 1

@@ -615,7 +615,7 @@ __device__ __forceinline__ uint32_t load_texel(const DeviceLevelView &lv, const 
 // blockIdx -> (pose, tile) keeps all tiles of a pose on one XCD (b % 8): its records stay in that
 // XCD's L2.
 // =================================================================================================
-template <bool STATS>
+template <bool STATS, int DBG = 0>  // DBG: timing experiments only (1 = skip the fine loop, 2 = reject tests but no pixel bodies)
 __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                      const uint4 *__restrict__ sorted,
                                                      const uint32_t *__restrict__ counts, uint32_t cap,
@@ -623,7 +623,8 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
                                                      int tiles_y, const uint2 *__restrict__ tile_hdr,
                                                      const uint32_t *__restrict__ entries, uint32_t entry_cap,
                                                      const uint32_t *__restrict__ overflow,
-                                                     uint32_t *__restrict__ vis, uint32_t *__restrict__ prim_out,
+                                                     uint32_t *__restrict__ vis, uint32_t vis16,
+                                                     uint32_t *__restrict__ prim_out,
                                                      unsigned long long *__restrict__ stats) {
   // STATS (debug builds of the launch only): [0] queue entries seen by waves, [1] past the quadrant bbox,
   // [2] past the lane-level rejection (__any(need)), [3] lanes needing, [4] fast bodies, [5] lanes in fast
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
     }
     __syncthreads();
     // ---- fine: each wave walks the queue for its own quadrant ------------------------------------
-    for (uint32_t j = 0; j < n; j++) {
+    for (uint32_t j = 0; j < (DBG == 1 ? 0u : n); j++) {
       const uint32_t qe = qidx[j];
       if (!((qe >> (28 + wave)) & 1u)) continue;  // this triangle cannot touch my quadrant (exact)
       const RasterRec &r = q[j].r;
@@ -749,6 +750,10 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
       const float rwf = fmaf(wa, wa > 0.0f ? pxhi : pxlo, fmaf(wb, wb > 0.0f ? pyhi : pylo, wc));
       const bool need = need0 & (rwf > 0.0f);
       if (!__any(need)) continue;
+      if (DBG == 2) {
+        if (need) best_r[0] = ridx;
+        continue;
+      }
       if (STATS) st[2]++, st[3] += (unsigned long long)__popcll(__ballot(need));
       // Fast path (exact): block fully inside the bbox, whole block inside the depth range and in front
       // of the eye, texture rectangle fully opaque.  Edge ties and depth ties are only *detected* here and
@@ -861,8 +866,13 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
     const int iy = by + ry;
     if (iy < height && bx < width) {
       const size_t o = ((size_t)pose * (size_t)height + (size_t)iy) * (size_t)width + (size_t)bx;
-      *reinterpret_cast<uint4 *>(vis + o) =
-          make_uint4(best_r[ry * 4], best_r[ry * 4 + 1], best_r[ry * 4 + 2], best_r[ry * 4 + 3]);
+      if (vis16)  // record indices fit 16 bits (0xFFFF = none): half the visibility traffic
+        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) =
+            make_uint2((best_r[ry * 4] & 0xFFFFu) | (best_r[ry * 4 + 1] << 16),
+                       (best_r[ry * 4 + 2] & 0xFFFFu) | (best_r[ry * 4 + 3] << 16));
+      else
+        *reinterpret_cast<uint4 *>(vis + o) =
+            make_uint4(best_r[ry * 4], best_r[ry * 4 + 1], best_r[ry * 4 + 2], best_r[ry * 4 + 3]);
       if (prim_out) {
         uint32_t p[4];
 #pragma unroll
@@ -948,7 +958,8 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
 // idx / d for idx < 2^24 by multiply-high (m, sh) computed and verified on the host
 __device__ __forceinline__ uint32_t fast_div(uint32_t idx, uint32_t m, uint32_t sh) { return __umulhi(idx, m) >> sh; }
 
-template <int FRAG_GROUP, int DBG>  // FRAG_GROUP: slabs whose visibility loads are in flight together; DBG: timing experiments only
+template <int FRAG_GROUP, int DBG, bool VIS16>  // FRAG_GROUP: slabs whose visibility loads are in flight together; DBG: timing
+                                                 // experiments only; VIS16: 16-bit visibility words (0xFFFF = none)
 __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
                                                        const uint32_t *__restrict__ vis, uint32_t n_poses,
@@ -973,6 +984,15 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
   if (pose >= n_poses) return;
   const TriRec *prec = recs + (size_t)pose * cap;
   const uint4 *pvis = reinterpret_cast<const uint4 *>(vis) + (size_t)pose * quads_per_pose;
+  const uint2 *pvis16 = reinterpret_cast<const uint2 *>(vis) + (size_t)pose * quads_per_pose;
+  constexpr uint32_t NONE_ID = VIS16 ? 0xFFFFu : NONE;
+  auto load_ids = [&](uint32_t q) {
+    if (VIS16) {
+      const uint2 v = pvis16[q];
+      return make_uint4(v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16);
+    }
+    return pvis[q];
+  };
   uint32_t *pfb = reinterpret_cast<uint32_t *>(fb) + (size_t)pose * quads_per_pose;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t *mylist = wlist[threadIdx.x >> 6];
@@ -985,10 +1005,11 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
     if (j < count) {
       const uint32_t qi = mylist[first + j];
       const uint32_t row = fast_div(qi, div_m, div_sh), qx = qi - row * quads_per_row;
-      const uint32_t id = vis[((size_t)pose * quads_per_pose + qi) * 4u + k];
+      const uint32_t id = VIS16 ? (uint32_t) reinterpret_cast<const uint16_t *>(vis)[((size_t)pose * quads_per_pose + qi) * 4u + k]
+                                : vis[((size_t)pose * quads_per_pose + qi) * 4u + k];
       uint32_t c = 0;
       const uint32_t pix = (row * quads_per_row + qx) * 4u + k;
-      if (id != NONE) {
+      if (id != NONE_ID) {
         const ShadeRec cur = prec[id].s;
         const float py = (float)row + 0.5f, px = (float)(qx * 4u + k) + 0.5f;
         c = shade_pixel(lv, cmap, cur, px, py, fmaf(cur.wp[1], py, cur.wp[2]), fmaf(cur.up[1], py, cur.up[2]),
@@ -1015,7 +1036,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
 #pragma unroll
     for (int u = 0; u < FRAG_GROUP; u++) {
       const uint32_t q = (chunk * FRAG_CHUNK + (uint32_t)(it0 + u)) * 256u + threadIdx.x;
-      idsv[u] = q < quads_per_pose ? ((DBG & 1) ? make_uint4(q & 63u, q & 63u, q & 63u, q & 63u) : pvis[q]) : make_uint4(NONE, NONE, NONE, NONE);
+      idsv[u] = q < quads_per_pose ? load_ids(q) : make_uint4(NONE_ID, NONE_ID, NONE_ID, NONE_ID);
     }
 #pragma unroll
     for (int u = 0; u < FRAG_GROUP; u++) {
@@ -1025,8 +1046,8 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
     const bool uniform = (ids.x == ids.y) & (ids.y == ids.z) & (ids.z == ids.w);
     bool done = false;
     uint32_t out = 0;
-    if (uniform & (ids.x == NONE)) done = true;  // background (or past the end: nothing is stored)
-    if (uniform & (ids.x != NONE) & (debug_leak_mod == 0u)) {
+    if (uniform & (ids.x == NONE_ID)) done = true;  // background (or past the end: nothing is stored)
+    if (uniform & (ids.x != NONE_ID) & (debug_leak_mod == 0u)) {
       const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[ids.x].s);
       const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
       const uint32_t flags = r3.z, tex = r3.w;
@@ -1148,8 +1169,9 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
                                                     const uint32_t *__restrict__ overflow,
                                                     const uint32_t *__restrict__ fix_count,
                                                     const uint2 *__restrict__ fix_list, uint32_t fix_cap,
-                                                    uint32_t *__restrict__ vis, uint32_t *__restrict__ prim_out,
-                                                    uint8_t *__restrict__ fb, uint32_t *__restrict__ error_flag) {
+                                                    uint32_t *__restrict__ vis, uint32_t vis16,
+                                                    uint32_t *__restrict__ prim_out, uint8_t *__restrict__ fb,
+                                                    uint32_t *__restrict__ error_flag) {
   const uint32_t total = *fix_count;
   if (total > fix_cap) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *error_flag = 1u;
@@ -1211,7 +1233,10 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
         colour = shade_pixel(lv, lv.colormap, sh, px, py, fmaf(sh.wp[1], py, sh.wp[2]), fmaf(sh.up[1], py, sh.up[2]),
                              fmaf(sh.vp[1], py, sh.vp[2]), width, height, poses[pose]) & 0xFFu;
       }
-      vis[o] = best_rec;
+      if (vis16)
+        reinterpret_cast<uint16_t *>(vis)[o] = (uint16_t)best_rec;  // NONE -> 0xFFFF
+      else
+        vis[o] = best_rec;
       if (prim_out) prim_out[o] = best_rec == NONE ? NONE : (uint32_t)(best & 0xFFFFFFull);
       fb[o] = (uint8_t)colour;
     }
@@ -1261,6 +1286,7 @@ struct rdoom_batch {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_copy = nullptr;  // H2D of h_poses finished: staging may be rewritten
   bool want_prim = false;
+  bool vis16 = false;  // record indices fit 16 bits: visibility words are u16
 };
 
 extern "C" {
@@ -1492,6 +1518,7 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   b->height = height;
   b->max_poses = max_poses;
   b->cap = level->ntri ? level->ntri : 1;
+  b->vis16 = b->cap < 0xFFFFu && getenv("RDOOM_VIS32") == nullptr;  // RDOOM_VIS32: tests force the 32-bit words
   const size_t npx = (size_t)width * height * max_poses;
   hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
@@ -1599,7 +1626,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof h, st));
     hipLaunchKernelGGL(raster_kernel<true>, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs,
                        b->d_sorted, b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
-                       b->entry_cap, b->d_overflow, b->d_vis, b->want_prim ? b->d_prim : nullptr, d_stats);
+                       b->entry_cap, b->d_overflow, b->d_vis, b->vis16 ? 1u : 0u, b->want_prim ? b->d_prim : nullptr, d_stats);
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     (void)hipFree(d_stats);
     const double waves = (double)nblocks * 4.0;
@@ -1612,9 +1639,11 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
             h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, (double)h[8] / (double)nblocks,
             (double)h[9] / (double)nblocks);
   } else {
-    hipLaunchKernelGGL(raster_kernel<false>, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs,
+    static const int raster_dbg = getenv("RDOOM_RASTER_DBG") ? atoi(getenv("RDOOM_RASTER_DBG")) : 0;  // timing experiments
+    auto rk = raster_dbg == 1 ? raster_kernel<false, 1> : (raster_dbg == 2 ? raster_kernel<false, 2> : raster_kernel<false, 0>);
+    hipLaunchKernelGGL(rk, dim3((uint32_t)nblocks), dim3(256), 0, st, lv->view, b->d_recs,
                        b->d_sorted, b->d_counts, b->cap, n, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
-                       b->entry_cap, b->d_overflow, b->d_vis, b->want_prim ? b->d_prim : nullptr,
+                       b->entry_cap, b->d_overflow, b->d_vis, b->vis16 ? 1u : 0u, b->want_prim ? b->d_prim : nullptr,
                        (unsigned long long *)nullptr);
   }
   if (tm) HIP_TRY(hipEventRecord(b->ev[2], st));
@@ -1639,16 +1668,16 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
   static const int frag_group = getenv("RDOOM_FRAG_GROUP") ? atoi(getenv("RDOOM_FRAG_GROUP")) : 1;  // tuning switch
   static const int frag_dbg = getenv("RDOOM_FRAG_DBG") ? atoi(getenv("RDOOM_FRAG_DBG")) : 0;  // timing experiments (wrong images)
-  auto frag = frag_group == 4 ? fragment_kernel<4, 0> : (frag_group == 2 ? fragment_kernel<2, 0> : fragment_kernel<1, 0>);
-  if (frag_dbg == 1) frag = fragment_kernel<1, 1>;
-  if (frag_dbg == 2) frag = fragment_kernel<1, 2>;
-  if (frag_dbg == 3) frag = fragment_kernel<1, 3>;
+  auto frag = b->vis16 ? fragment_kernel<1, 0, true> : fragment_kernel<1, 0, false>;
+  if (frag_group == 2) frag = b->vis16 ? fragment_kernel<2, 0, true> : fragment_kernel<2, 0, false>;
+  if (frag_dbg == 2) frag = b->vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>;
   hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv->view, b->d_recs, b->cap, b->d_poses,
                      b->d_vis, n, fblocks, qpp, qpr, div_m, div_sh, W, H, b->d_fb, b->d_fix_count, b->d_fix_list,
                      b->fix_cap, debug_leak_mod);
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap,
                      b->d_poses, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow,
-                     b->d_fix_count, b->d_fix_list, b->fix_cap, b->d_vis, b->want_prim ? b->d_prim : nullptr, b->d_fb,
+                     b->d_fix_count, b->d_fix_list, b->fix_cap, b->d_vis, b->vis16 ? 1u : 0u,
+                     b->want_prim ? b->d_prim : nullptr, b->d_fb,
                      b->d_fix_count + 1);
   HIP_TRY(hipGetLastError());
   if (tm) {

@@ -4,7 +4,8 @@
                           rule (all candidates of the tile, lexicographic (depth, primitive) minimum) re-resolves
                           ordinary pixels -- output must be unchanged;
   RDOOM_NO_BINS=1         the rasteriser's fallback scan (no per-tile bins), as used when a pose overflows them;
-  RDOOM_ENTRY_CAP=n       tile-list entries per pose the binning kernel may emit, to force that overflow."""
+  RDOOM_ENTRY_CAP=n       tile-list entries per pose the binning kernel may emit, to force that overflow;
+  RDOOM_VIS32=1           32-bit visibility words (levels with >= 65535 triangles) instead of 16-bit ones."""
 import os
 import re
 import subprocess
@@ -40,6 +41,15 @@ def test_tile_list_overflow_falls_back_to_the_scan():
     """RDOOM_ENTRY_CAP=300: nearly every pose needs more tile-list entries than that, sets its overflow flag and is rasterised by the scan"""
     bad, _ = run_child({'RDOOM_ENTRY_CAP': '300'})
     assert bad == 0
+
+
+def test_32_bit_visibility_words():
+    """RDOOM_VIS32=1: the visibility buffer keeps 32-bit record indices (the format used when a level has 65535 or
+    more triangles) instead of the 16-bit words the synthetic levels qualify for"""
+    bad, _ = run_child({'RDOOM_VIS32': '1'})
+    assert bad == 0
+    bad, fixups = run_child({'RDOOM_VIS32': '1', 'RDOOM_DEBUG_LEAK_MOD': '101'})
+    assert bad == 0 and fixups > 3000
 
 
 def test_child_case_plain():
