@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(DeviceLevelView lv, cons
 // by the general per-pixel body, lane per pixel -- same results, one code path for everything unusual.
 // =================================================================================================
 constexpr int FRAG_CHUNK = 16;
-constexpr int FRAG_WLIST = 128;  // per-wave list of unfinished quads: at most 15 carried over + 64 new
+constexpr int FRAG_WLIST = 160;  // per-wave list of unfinished quads: at most 15 carried over + 64 x 2 new
 
 __device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const uint8_t *cmap, float px, float py,
                                               int width, int height, float vr0, float vr1) {
@@ -958,8 +958,8 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
 // idx / d for idx < 2^24 by multiply-high (m, sh) computed and verified on the host
 __device__ __forceinline__ uint32_t fast_div(uint32_t idx, uint32_t m, uint32_t sh) { return __umulhi(idx, m) >> sh; }
 
-template <int FRAG_GROUP, int DBG, bool VIS16>  // FRAG_GROUP: slabs whose visibility loads are in flight together; DBG: timing
-                                                 // experiments only; VIS16: 16-bit visibility words (0xFFFF = none)
+template <int NQ, int DBG, bool VIS16>  // NQ: adjacent quads per lane (1 or 2; the frame width is a multiple of 4 NQ);
+                                        // DBG: timing experiments only; VIS16: 16-bit visibility words (0xFFFF = none)
 __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
                                                        const uint32_t *__restrict__ vis, uint32_t n_poses,
@@ -968,6 +968,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
                                                        int width, int height, uint8_t *__restrict__ fb,
                                                        uint32_t *__restrict__ fix_count, uint2 *__restrict__ fix_list,
                                                        uint32_t fix_cap, uint32_t debug_leak_mod) {
+  constexpr int NP = 2 * NQ, NPX = 4 * NQ;  // float2 pairs and pixels per lane
   __shared__ uint8_t cmap[32 * 256];
   __shared__ uint32_t wlist[4][FRAG_WLIST];
   {
@@ -983,16 +984,9 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
   const uint32_t chunk = g % chunks_per_pose;
   if (pose >= n_poses) return;
   const TriRec *prec = recs + (size_t)pose * cap;
-  const uint4 *pvis = reinterpret_cast<const uint4 *>(vis) + (size_t)pose * quads_per_pose;
-  const uint2 *pvis16 = reinterpret_cast<const uint2 *>(vis) + (size_t)pose * quads_per_pose;
   constexpr uint32_t NONE_ID = VIS16 ? 0xFFFFu : NONE;
-  auto load_ids = [&](uint32_t q) {
-    if (VIS16) {
-      const uint2 v = pvis16[q];
-      return make_uint4(v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16);
-    }
-    return pvis[q];
-  };
+  const uint32_t *pvis32 = vis + (size_t)pose * quads_per_pose * 4u;
+  const uint16_t *pvis16 = reinterpret_cast<const uint16_t *>(vis) + (size_t)pose * quads_per_pose * 4u;
   uint32_t *pfb = reinterpret_cast<uint32_t *>(fb) + (size_t)pose * quads_per_pose;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t *mylist = wlist[threadIdx.x >> 6];
@@ -1005,8 +999,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
     if (j < count) {
       const uint32_t qi = mylist[first + j];
       const uint32_t row = fast_div(qi, div_m, div_sh), qx = qi - row * quads_per_row;
-      const uint32_t id = VIS16 ? (uint32_t) reinterpret_cast<const uint16_t *>(vis)[((size_t)pose * quads_per_pose + qi) * 4u + k]
-                                : vis[((size_t)pose * quads_per_pose + qi) * 4u + k];
+      const uint32_t id = VIS16 ? (uint32_t)pvis16[(size_t)qi * 4u + k] : pvis32[(size_t)qi * 4u + k];
       uint32_t c = 0;
       const uint32_t pix = (row * quads_per_row + qx) * 4u + k;
       if (id != NONE_ID) {
@@ -1028,27 +1021,45 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
       if (k == 0) pfb[qi] = v;
     }
   };
-  // The visibility words of FRAG_GROUP slabs are requested back to back (they stream from HBM; the record and
-  // texel gathers behind them hit L2), so one HBM latency is paid per group instead of per slab.
-  for (int it0 = 0; it0 < FRAG_CHUNK; it0 += FRAG_GROUP) {
-    if ((chunk * FRAG_CHUNK + (uint32_t)it0) * 256u + (threadIdx.x - lane) >= quads_per_pose) break;  // wave-uniform
-    uint4 idsv[FRAG_GROUP];
+  const uint32_t units_per_pose = quads_per_pose / (uint32_t)NQ;  // a unit = the NQ adjacent quads of one lane
+  for (int it = 0; it < FRAG_CHUNK; it++) {
+    const uint32_t ui = (chunk * FRAG_CHUNK + (uint32_t)it) * 256u + threadIdx.x;
+    if (ui - lane >= units_per_pose) break;  // wave-uniform: the whole wave is past the end of the frame
+    const bool valid = ui < units_per_pose;
+    const uint32_t q0 = ui * (uint32_t)NQ;
+    // visibility words of my NPX pixels
+    uint32_t id[NPX];
 #pragma unroll
-    for (int u = 0; u < FRAG_GROUP; u++) {
-      const uint32_t q = (chunk * FRAG_CHUNK + (uint32_t)(it0 + u)) * 256u + threadIdx.x;
-      idsv[u] = q < quads_per_pose ? load_ids(q) : make_uint4(NONE_ID, NONE_ID, NONE_ID, NONE_ID);
+    for (int k = 0; k < NPX; k++) id[k] = NONE_ID;
+    if (valid) {
+      if (VIS16) {
+        if (NQ == 2) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(pvis16 + (size_t)q0 * 4u);
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < NPX; k++) id[k] = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu);
+        } else {
+          const uint2 v = *reinterpret_cast<const uint2 *>(pvis16 + (size_t)q0 * 4u);
+          id[0] = v.x & 0xFFFFu, id[1] = v.x >> 16, id[2] = v.y & 0xFFFFu, id[3] = v.y >> 16;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(pvis32 + ((size_t)q0 + (size_t)q) * 4u);
+          id[4 * q] = v.x, id[4 * q + 1] = v.y, id[4 * q + 2] = v.z, id[4 * q + 3] = v.w;
+        }
+      }
     }
+    bool uniform = true;
 #pragma unroll
-    for (int u = 0; u < FRAG_GROUP; u++) {
-    const uint32_t qi = (chunk * FRAG_CHUNK + (uint32_t)(it0 + u)) * 256u + threadIdx.x;
-    const bool valid = qi < quads_per_pose;
-    const uint4 ids = idsv[u];
-    const bool uniform = (ids.x == ids.y) & (ids.y == ids.z) & (ids.z == ids.w);
+    for (int k = 1; k < NPX; k++) uniform &= id[k] == id[0];
     bool done = false;
-    uint32_t out = 0;
-    if (uniform & (ids.x == NONE_ID)) done = true;  // background (or past the end: nothing is stored)
-    if (uniform & (ids.x != NONE_ID) & (debug_leak_mod == 0u)) {
-      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[ids.x].s);
+    uint32_t out[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) out[q] = 0;
+    if (uniform & (id[0] == NONE_ID)) done = true;  // background (or past the end: nothing is stored)
+    if (uniform & (id[0] != NONE_ID) & (debug_leak_mod == 0u)) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[id[0]].s);
       const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
       const uint32_t flags = r3.z, tex = r3.w;
       // (all four loads are issued before the flag is examined: one memory latency, not two)
@@ -1059,87 +1070,101 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
                     va = __uint_as_float(r1.z), vb = __uint_as_float(r1.w), vc = __uint_as_float(r2.x),
                     atlas_u = __uint_as_float(r2.y), atlas_v = __uint_as_float(r2.z), size_x = __uint_as_float(r2.w),
                     size_y = __uint_as_float(r3.x), light = __uint_as_float(r3.y);
-        const uint32_t row = fast_div(qi, div_m, div_sh), qx = qi - row * quads_per_row;
+        const uint32_t row = fast_div(q0, div_m, div_sh), qx = q0 - row * quads_per_row;
         const float py = (float)row + 0.5f;
         const float px0 = (float)(qx * 4u) + 0.5f;
-        const f32x2 pxa = {px0, px0 + 1.0f}, pxb = {px0 + 2.0f, px0 + 3.0f};
         const float row_w = fmaf(wb, py, wc), row_u = fmaf(ub, py, uc), row_v = fmaf(vb, py, vc);
-        // F1
-        const f32x2 rwa = pk_fma(splat(wa), pxa, splat(row_w)), rwb = pk_fma(splat(wa), pxb, splat(row_w));
-        const float rw_lo = fminf(rwa.x, rwb.y), rw_hi = fmaxf(rwa.x, rwb.y);  // rw is monotone along the quad
-        const bool in_range = (rw_lo >= 0x1p-100f) & (rw_hi <= 0x1p100f);
-        const f32x2 wwa = exact_rcp2(rwa), wwb = exact_rcp2(rwb);
-        const f32x2 tua = pk_fma(splat(ua), pxa, splat(row_u)) * wwa, tub = pk_fma(splat(ua), pxb, splat(row_u)) * wwb;
-        const f32x2 tva = pk_fma(splat(va), pxa, splat(row_v)) * wwa, tvb = pk_fma(splat(va), pxb, splat(row_v)) * wwb;
-        // F2: mod(t, size) = t - size * floor(t / size).  q0 = t * RN(1/size) equals the quotient exactly for a
-        // power-of-two size; for an integer size it is within |t/size| * 2^-23 of it, and the remainder test
-        // below certifies floor(q0) == floor(RN(t / size)) (else the quad goes to the general body).
+        // F2 preparation: q0 = t * RN(1/size) equals the quotient exactly for a power-of-two size; for an integer
+        // size it is within |t/size| * 2^-23 of it, and the remainder test below certifies
+        // floor(q0) == floor(RN(t / size)) (else the run goes to the general body).
         const f32x2 inv_s = exact_rcp2(f32x2{size_x, size_y});
-        f32x2 qa = tua * splat(inv_s.x), qb = tub * splat(inv_s.x);
-        qa = f32x2{floorf(qa.x), floorf(qa.y)};
-        qb = f32x2{floorf(qb.x), floorf(qb.y)};
-        const f32x2 rxa = pk_fma(splat(-size_x), qa, tua), rxb = pk_fma(splat(-size_x), qb, tub);
-        const f32x2 uxa = rxa + splat(atlas_u), uxb = rxb + splat(atlas_u);
-        f32x2 ha = tva * splat(inv_s.y), hb = tvb * splat(inv_s.y);
-        ha = f32x2{floorf(ha.x), floorf(ha.y)};
-        hb = f32x2{floorf(hb.x), floorf(hb.y)};
-        const f32x2 rya = pk_fma(splat(-size_y), ha, tva), ryb = pk_fma(splat(-size_y), hb, tvb);
-        const f32x2 uya = rya + splat(atlas_v), uyb = ryb + splat(atlas_v);
-        bool mod_ok = true;
-        if (__any((flags & SHADE_NP2) != 0u)) {
-          // Certificate (integer size y, t = x): with guard = 2^-20 * max(|x|, y), guard <= r <= y - guard and
-          // |x| < 2^23 imply that no integer lies between x * RN(1/y) and RN(x / y) (both are within
-          // |x/y| * 2^-22 of x/y, i.e. the true remainder is more than |x| * 2^-22 away from 0 and from y),
-          // and that y * floor is exact.  Power-of-two axes always pass.
-          const bool p2x = (flags & SHADE_POW2_X) != 0u, p2y = (flags & SHADE_POW2_Y) != 0u;
-          mod_ok = mod_cert(tua.x, rxa.x, size_x, p2x) & mod_cert(tua.y, rxa.y, size_x, p2x) & mod_cert(tub.x, rxb.x, size_x, p2x) &
-                   mod_cert(tub.y, rxb.y, size_x, p2x) & mod_cert(tva.x, rya.x, size_y, p2y) & mod_cert(tva.y, rya.y, size_y, p2y) &
-                   mod_cert(tvb.x, ryb.x, size_y, p2y) & mod_cert(tvb.y, ryb.y, size_y, p2y);
-        }
-        // F3
+        // F3 parameters: one u16 texel store, REPEAT = masks
         const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
         const uint32_t base2 = base * 2u;  // byte offsets < 2^27: one 32-bit VGPR offset from the uniform base pointer
         const char *tb = reinterpret_cast<const char *>(lv.texels);
-        const uint32_t o0 = (((uint32_t)cvt_floor_i32(uya.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxa.x) & wm);
-        const uint32_t o1 = (((uint32_t)cvt_floor_i32(uya.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxa.y) & wm);
-        const uint32_t o2 = (((uint32_t)cvt_floor_i32(uyb.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxb.x) & wm);
-        const uint32_t o3 = (((uint32_t)cvt_floor_i32(uyb.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(uxb.y) & wm);
-        const uint32_t t0 = (DBG & 2) ? (o0 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o0 * 2u + base2)),
-                       t1 = (DBG & 2) ? (o1 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o1 * 2u + base2)),
-                       t2 = (DBG & 2) ? (o2 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o2 * 2u + base2)),
-                       t3 = (DBG & 2) ? (o3 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o3 * 2u + base2));
-        // F4, F5 at the two end pixels; the middle pixels only when the ends disagree
+        // Certificate for integer (non-power-of-two) tile sizes, evaluated only in waves that hold such a record:
+        // with guard = 2^-20 * max(|x|, y), guard <= r <= y - guard and |x| < 2^23 imply that no integer lies between
+        // x * RN(1/y) and RN(x / y) and that y * floor is exact (fastmath.hpp).  Power-of-two axes always pass.
+        const bool any_np2 = __any((flags & SHADE_NP2) != 0u);
+        const bool p2x = (flags & SHADE_POW2_X) != 0u, p2y = (flags & SHADE_POW2_Y) != 0u;
+        bool mod_ok = true;
+        f32x2 ww[NP];
+        uint32_t texel[NPX], any_texel = 0;
+        float rw_first = 0.0f, rw_last = 0.0f;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {  // one pair of pixels at a time, straight through to its two texel loads
+          const f32x2 px = {px0 + (float)(2 * p), px0 + (float)(2 * p + 1)};
+          const f32x2 rw = pk_fma(splat(wa), px, splat(row_w));  // F1
+          if (p == 0) rw_first = rw.x;
+          if (p == NP - 1) rw_last = rw.y;
+          ww[p] = exact_rcp2(rw);
+          const f32x2 tu = pk_fma(splat(ua), px, splat(row_u)) * ww[p];
+          const f32x2 tv = pk_fma(splat(va), px, splat(row_v)) * ww[p];
+          f32x2 fq = tu * splat(inv_s.x);  // F2: mod(t, size) = t - size * floor(t / size)
+          fq = f32x2{floorf(fq.x), floorf(fq.y)};
+          const f32x2 rx = pk_fma(splat(-size_x), fq, tu);
+          f32x2 fh = tv * splat(inv_s.y);
+          fh = f32x2{floorf(fh.x), floorf(fh.y)};
+          const f32x2 ry = pk_fma(splat(-size_y), fh, tv);
+          if (any_np2)
+            mod_ok = mod_ok & mod_cert(tu.x, rx.x, size_x, p2x) & mod_cert(tu.y, rx.y, size_x, p2x) &
+                     mod_cert(tv.x, ry.x, size_y, p2y) & mod_cert(tv.y, ry.y, size_y, p2y);
+          const f32x2 ux = rx + splat(atlas_u), uy = ry + splat(atlas_v);  // F3
+          const uint32_t o0 = (((uint32_t)cvt_floor_i32(uy.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.x) & wm);
+          const uint32_t o1 = (((uint32_t)cvt_floor_i32(uy.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.y) & wm);
+          texel[2 * p] = (DBG & 2) ? (o0 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o0 * 2u + base2));
+          texel[2 * p + 1] = (DBG & 2) ? (o1 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o1 * 2u + base2));
+        }
+        // rw is monotone along the run: both ends inside the verified range of the exact reciprocal forms
+        const bool in_range = (fminf(rw_first, rw_last) >= 0x1p-100f) & (fmaxf(rw_first, rw_last) <= 0x1p100f);
+#pragma unroll
+        for (int k = 0; k < NPX; k++) any_texel |= texel[k];
+        // F4, F5 at the two end pixels; the pixels between them only when the ends disagree
         auto rows_of = [&](f32x2 dist) {
           const f32x2 dterm = splat(1.0f) - exact_div09_2(dist + splat(0.9f));
           const f32x2 lgt = splat(light * 2.0f) - f32x2{fminf(1.0f, dterm.x), fminf(1.0f, dterm.y)};
           const f32x2 tt = (splat(1.0f) - lgt) * splat(32.0f);
           return f32x2{fminf(fmaxf(floorf(tt.x), 0.0f), 31.0f), fminf(fmaxf(floorf(tt.y), 0.0f), 31.0f)};
         };
-        const f32x2 rf_ends = rows_of(f32x2{wwa.x, wwb.y});
-        f32x2 rf_mid = splat(rf_ends.x);
-        if (rf_ends.x != rf_ends.y) rf_mid = rows_of(f32x2{wwa.y, wwb.x});
-        const bool opaque = ((t0 | t1 | t2 | t3) & 0x8000u) == 0u;
+        const f32x2 rf_ends = rows_of(f32x2{ww[0].x, ww[NP - 1].y});
+        f32x2 rf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) rf[p] = splat(rf_ends.x);
+        if (rf_ends.x != rf_ends.y) {
+#pragma unroll
+          for (int p = 0; p < NP; p++) rf[p] = rows_of(ww[p]);
+        }
+        const bool opaque = (any_texel & 0x8000u) == 0u;
         if (in_range & mod_ok & opaque) {
-          const uint32_t c0 = cmap[((uint32_t)(int)rf_ends.x << 8) | (t0 & 0xFFu)],
-                         c1 = cmap[((uint32_t)(int)rf_mid.x << 8) | (t1 & 0xFFu)],
-                         c2 = cmap[((uint32_t)(int)rf_mid.y << 8) | (t2 & 0xFFu)],
-                         c3 = cmap[((uint32_t)(int)rf_ends.y << 8) | (t3 & 0xFFu)];
-          out = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+#pragma unroll
+          for (int p = 0; p < NP; p++) {
+            const uint32_t c0 = cmap[((uint32_t)(int)rf[p].x << 8) | (texel[2 * p] & 0xFFu)],
+                           c1 = cmap[((uint32_t)(int)rf[p].y << 8) | (texel[2 * p + 1] & 0xFFu)];
+            out[p >> 1] |= (c0 | (c1 << 8)) << (16 * (p & 1));
+          }
           done = true;
         }
       }
     }
-    if (done & valid) pfb[qi] = out;
+    if (done & valid) {
+      if (NQ == 2)
+        *reinterpret_cast<uint2 *>(pfb + q0) = make_uint2(out[0], out[NQ - 1]);
+      else
+        pfb[q0] = out[0];
+    }
     const unsigned long long sm = __ballot(!done);
     if (sm) {  // ordered append of this wave's unfinished quads, then shade full groups of 16
-      if (!done) mylist[wn + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = qi;
-      wn += (uint32_t)__popcll(sm);
+      if (!done) {
+        const uint32_t at = wn + (uint32_t)NQ * (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int q = 0; q < NQ; q++) mylist[at + (uint32_t)q] = q0 + (uint32_t)q;
+      }
+      wn += (uint32_t)NQ * (uint32_t)__popcll(sm);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       while (wn >= 16u) {
         wn -= 16u;
         shade_listed(wn, 16u);
       }
-    }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1661,16 +1686,19 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
         (hi < qpp && (uint32_t)(((uint64_t)hi * div_m) >> 32) >> div_sh != k))
       return rdoom::fail(RDOOM_BAD_ARG, "internal: fast_div constants invalid for width %d", W);
   }
-  const uint32_t fblocks = (qpp + FRAG_CHUNK * 256 - 1) / (FRAG_CHUNK * 256);
   static const uint32_t debug_leak_mod = getenv("RDOOM_DEBUG_LEAK_MOD") ? (uint32_t)atoi(getenv("RDOOM_DEBUG_LEAK_MOD")) : 0u;
+  static const int frag_nq_env = getenv("RDOOM_FRAG_NQ") ? atoi(getenv("RDOOM_FRAG_NQ")) : 2;  // tuning switch / tests
+  static const int frag_dbg = getenv("RDOOM_FRAG_DBG") ? atoi(getenv("RDOOM_FRAG_DBG")) : 0;  // timing experiments (wrong images)
+  const int nq = (frag_nq_env == 2 && W % 8 == 0) ? 2 : 1;  // quads per lane: two when rows divide into 8-pixel runs
+  const uint32_t units = qpp / (uint32_t)nq;
+  const uint32_t fblocks = (units + FRAG_CHUNK * 256 - 1) / (FRAG_CHUNK * 256);
   HIP_TRY(hipMemsetAsync(b->d_fix_count, 0, 2 * sizeof(uint32_t), st));
   const uint64_t fgrid = (uint64_t)((n + 7) / 8) * 8ull * fblocks;
   if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
-  static const int frag_group = getenv("RDOOM_FRAG_GROUP") ? atoi(getenv("RDOOM_FRAG_GROUP")) : 1;  // tuning switch
-  static const int frag_dbg = getenv("RDOOM_FRAG_DBG") ? atoi(getenv("RDOOM_FRAG_DBG")) : 0;  // timing experiments (wrong images)
-  auto frag = b->vis16 ? fragment_kernel<1, 0, true> : fragment_kernel<1, 0, false>;
-  if (frag_group == 2) frag = b->vis16 ? fragment_kernel<2, 0, true> : fragment_kernel<2, 0, false>;
+  auto frag = nq == 2 ? (b->vis16 ? fragment_kernel<2, 0, true> : fragment_kernel<2, 0, false>)
+                      : (b->vis16 ? fragment_kernel<1, 0, true> : fragment_kernel<1, 0, false>);
   if (frag_dbg == 2) frag = b->vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>;
+
   hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv->view, b->d_recs, b->cap, b->d_poses,
                      b->d_vis, n, fblocks, qpp, qpr, div_m, div_sh, W, H, b->d_fb, b->d_fix_count, b->d_fix_list,
                      b->fix_cap, debug_leak_mod);

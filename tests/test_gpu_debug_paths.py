@@ -5,6 +5,7 @@
                           ordinary pixels -- output must be unchanged;
   RDOOM_NO_BINS=1         the rasteriser's fallback scan (no per-tile bins), as used when a pose overflows them;
   RDOOM_ENTRY_CAP=n       tile-list entries per pose the binning kernel may emit, to force that overflow;
+  RDOOM_FRAG_NQ=1         one quad per lane in the fragment kernel (default two when the width is a multiple of 8);
   RDOOM_VIS32=1           32-bit visibility words (levels with >= 65535 triangles) instead of 16-bit ones."""
 import os
 import re
@@ -50,6 +51,12 @@ def test_32_bit_visibility_words():
     assert bad == 0
     bad, fixups = run_child({'RDOOM_VIS32': '1', 'RDOOM_DEBUG_LEAK_MOD': '101'})
     assert bad == 0 and fixups > 3000
+
+
+def test_one_quad_per_lane_fragment_kernel():
+    """RDOOM_FRAG_NQ=1: the fragment kernel variant used for frame widths that are not a multiple of 8"""
+    bad, _ = run_child({'RDOOM_FRAG_NQ': '1'})
+    assert bad == 0
 
 
 def test_child_case_plain():

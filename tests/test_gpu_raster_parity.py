@@ -71,7 +71,14 @@ def test_static_plus_sky_sweep(oracle_levels):
 def test_kat_level_and_odd_sizes(oracle_levels):
     lv = oracle_levels(1)
     run_case(lv, 64, 33, 6, rd.ALL_KINDS)      # partial tiles in both directions
+    run_case(lv, 324, 201, 4, rd.ALL_KINDS)    # width a multiple of 4 but not of 8: one quad per lane
     run_case(lv, 1920, 1080, 2, rd.ALL_KINDS)  # BASELINE resolution
+
+
+def test_4k_time_varying(oracle_levels):
+    """BASELINE config 5's frame size (3840x2160) with animated flats, scrolling walls and the per-pose light
+    table at t != 0, on the synthetic E1M3 (no DOOM2.WAD exists here): 2040 tiles per frame, 8.3 Mpixel."""
+    run_case(oracle_levels(2), 3840, 2160, 2, rd.ALL_KINDS, time=2.3)
 
 
 def test_time_varying(oracle_levels):
