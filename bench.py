@@ -54,15 +54,21 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # one process per GPU; RDOOM_DIST_BACKEND=gloo (with ranks wrapped onto the GPUs present) exists only so that the
+    # N > 1 code path can be exercised on a one-GPU box
+    backend = os.environ.get('RDOOM_DIST_BACKEND', 'nccl')
+    device_index = local_rank if backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device_index))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
-        torch.cuda.set_device(local_rank)
-    rd.set_device(local_rank)
+    rd.set_device(device_index)
 
     iwad = args.iwad or ensure_wad()
     meta = args.metadata or META_PATH
@@ -95,7 +101,7 @@ def main():
         fixups = t['fixup_pixels']
     barrier()
     elapsed = time.perf_counter() - t_start
-    elapsed = sharding.max_over_ranks(elapsed, dist, 'cuda')
+    elapsed = sharding.max_over_ranks(elapsed, dist, 'cuda' if backend == 'nccl' else 'cpu')
 
     if rank == 0:
         px_per_step = args.poses * args.width * args.height
@@ -106,7 +112,9 @@ def main():
         pmc = os.path.join(ROOT, 'profiles', 'pmc_fragment_latest.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+                rec = json.load(open(pmc))  # PMC passes of an earlier profile run (tools/profile_round.sh) on this workload
+                if (rec.get('poses'), rec.get('width'), rec.get('height')) == (args.poses, args.width, args.height):
+                    traffic = rec.get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
         cpu = None

@@ -23,8 +23,10 @@ def ensure_wad():
         import mkwad
         wad, _ = mkwad.build_wad(1993)
         os.makedirs(GOLDEN, exist_ok=True)
-        with open(WAD_PATH, 'wb') as f:
+        tmp = '%s.%d.tmp' % (WAD_PATH, os.getpid())  # several ranks may get here at once: write aside, then rename
+        with open(tmp, 'wb') as f:
             f.write(wad)
+        os.replace(tmp, WAD_PATH)
     return WAD_PATH
 
 
