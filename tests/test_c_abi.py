@@ -82,3 +82,29 @@ def test_pose_look_matches_numpy_camera():
     assert np.allclose(p['projection'], reference_projection(1920, 1080), rtol=0, atol=1e-6)
     assert np.allclose(p['modelview'], view_matrix((1.0, 0.5, -2.0), 0.7, -0.2), rtol=0, atol=1e-6)
     assert p['time'] == np.float32(0.25)
+
+
+def test_level_create_validates_before_touching_the_device():
+    """bad descriptors are rejected with RDOOM_BAD_ARG (-1) on a box without a GPU too"""
+    from test_kat_analytic import kat_level
+    lvl, _ = kat_level()
+    bad = dict(lvl)
+    bad['wall_atlas'] = np.zeros((100, 64), np.uint16)  # not a power of two (tex.rs:183-200 guarantees one)
+    with pytest.raises(rd.RdoomError) as e:
+        rd.DeviceLevel(bad)
+    assert e.value.status == -1 and 'power of two' in str(e.value)
+    bad = dict(lvl)
+    bad['draws'] = np.array([[1, 0, 0, 5]], np.uint32)  # index count not a multiple of 3
+    with pytest.raises(rd.RdoomError) as e:
+        rd.DeviceLevel(bad)
+    assert e.value.status == -1
+    bad = dict(lvl)
+    bad['draws'] = np.array([[7, 0, 0, 3]], np.uint32)  # unknown kind
+    with pytest.raises(rd.RdoomError) as e:
+        rd.DeviceLevel(bad)
+    assert e.value.status == -1
+    bad = dict(lvl)
+    bad['static_indices'] = np.array([0, 1, 999] + [0] * 12, np.uint32)  # vertex index out of range
+    with pytest.raises(rd.RdoomError) as e:
+        rd.DeviceLevel(bad)
+    assert e.value.status == -1

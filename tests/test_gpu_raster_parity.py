@@ -167,3 +167,35 @@ def test_moving_objects(oracle_levels):
     fb_rest = batch.read_framebuffer()
     batch.render(poses, lights)
     assert np.array_equal(fb_rest, batch.read_framebuffer())
+
+
+def test_edge_cases(oracle_levels):
+    """empty level, nothing selected, smallest frame, batch bounds"""
+    from test_kat_analytic import kat_level
+    lvl, lights = kat_level()
+    empty = dict(lvl)
+    empty['draws'] = np.zeros((0, 4), np.uint32)
+    poses = np.zeros(2, rd.POSE)
+    poses['modelview'] = np.eye(4, dtype=np.float32).reshape(16)
+    poses['projection'] = reference_projection(64, 40)
+    b = rd.Batch(rd.DeviceLevel(empty), 64, 40, 2)
+    b.render(poses, lights)
+    assert not b.read_framebuffer().any()                       # no triangles: background everywhere
+    dev = rd.DeviceLevel(lvl)
+    b = rd.Batch(dev, 64, 40, 2)
+    b.render(poses, lights, kinds=0)
+    assert not b.read_framebuffer().any()                       # no kind selected
+    b.render(poses[:1], lights)                                 # fewer poses than the batch holds
+    one = b.read_framebuffer()
+    assert one.shape == (1, 40, 64) and one.any()
+    with pytest.raises(rd.RdoomError):
+        b.render(np.zeros(3, rd.POSE), lights)                  # more poses than max_poses
+    with pytest.raises(rd.RdoomError):
+        rd.Batch(dev, 66, 40, 1)                                # width must be a multiple of 4
+    small = rd.Batch(dev, 8, 1, 1)                              # one row of eight pixels
+    p = np.zeros(1, rd.POSE)
+    p['modelview'] = np.eye(4, dtype=np.float32).reshape(16)
+    p['projection'] = reference_projection(8, 1)
+    small.render(p, lights)
+    want = raster.RasterOracle(lvl).render(p[0]['modelview'], p[0]['projection'], 0.0, lights, 8, 1)
+    assert np.array_equal(small.read_framebuffer()[0], want)
