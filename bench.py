@@ -133,7 +133,7 @@ def main():
             cpu = {'value': round(n * args.width * args.height / tc / 1e6, 3), 'unit': 'Mpixels/s',
                    'cores': min(cores, n), 'kind': 'port',
                    'sample': '%d poses of the same sweep at %dx%d, oracle/raster_oracle.c, %.1f s; level build '
-                             '(product C++ walk) %.1f ms' % (n, args.width, args.height, tc, t_build * 1e3)}
+                             '(C++ walk + device tessellation kernels, first use) %.1f ms' % (n, args.width, args.height, tc, t_build * 1e3)}
         out = {
             'metric': 'Mpixels/s, E1M1 1920x1080 pose batch', 'value': round(total_px / elapsed / 1e6, 1),
             'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
