@@ -127,7 +127,7 @@ __device__ __forceinline__ float glsl_mod(float x, float y) { return x - y * flo
 // triangles.  The order only affects speed: the winner is the lexicographic min of (d24, primitive).
 // =================================================================================================
 constexpr uint32_t SORT_BUCKETS = 2048;
-constexpr uint32_t SORT_KEY_CAP = 24576;  // triangles per pose whose keys fit the LDS key array
+constexpr uint32_t SORT_KEY_CAP = 8192;  // visible triangles per pose whose keys fit the LDS key array (more: unsorted, still correct)
 
 __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const PoseConst &pc,
                                                const ObjectConst *__restrict__ objs, uint32_t t, int width,
@@ -420,27 +420,28 @@ __device__ __forceinline__ bool tile_may_touch(const uint4 c0, const uint4 c1, c
 }
 
 // =================================================================================================
-// Kernel 1b: binning.  One 512-thread workgroup per pose turns the near-to-far record list into
+// Kernel 1b: binning.  One workgroup per pose turns the near-to-far record list into
 // per-tile lists: count -> scan -> fill.  The unit of work is a (triangle, tile of its bbox) pair: the
 // raster coefficients of BIN_CHUNK triangles are staged in LDS together with an exclusive prefix sum of
 // their bbox tile counts, and every lane finds its pair by binary search in that prefix -- lanes stay busy
 // whatever the mix of one-tile and whole-frame triangles, and the exact tile/quadrant test runs from LDS.
-// entry = record index | quadrant mask << 28.  Pairs are visited in list order 512 at a time, so a tile's
+// entry = record index | quadrant mask << 28.  Pairs are visited in list order one workgroup-full at a time, so a tile's
 // list is near-to-far up to that window; the rasteriser re-sorts each list chunk by record index (= depth
 // rank).  Order only affects early-z efficiency: the winner is order-independent.  If a pose needs more than
 // entry_cap entries (or the frame has more than MAX_TILES tiles) its overflow flag is set and the
 // rasteriser scans the sorted list instead.
 // =================================================================================================
 constexpr uint32_t MAX_TILES = 8192;
-constexpr int BIN_THREADS = 512;
-constexpr uint32_t BIN_CHUNK = 512;  // triangles staged per round: one per thread
 
+template <int BIN_THREADS, int BIN_LOG2>  // threads per workgroup = triangles staged per round (one per thread)
 __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restrict__ recs,
                                                           const uint4 *__restrict__ sorted,
                                                           const uint32_t *__restrict__ counts, uint32_t cap,
                                                           int tiles_x, int tiles_y, uint2 *__restrict__ tile_hdr,
                                                           uint32_t *__restrict__ entries, uint32_t entry_cap,
                                                           uint32_t *__restrict__ overflow) {
+  constexpr uint32_t BIN_CHUNK = BIN_THREADS;
+  static_assert((1 << BIN_LOG2) == BIN_THREADS, "bin_kernel: BIN_LOG2");
   extern __shared__ uint32_t bin_dyn[];  // tile_cnt[T], tile_off[T]
   __shared__ uint4 coef[BIN_CHUNK][3];   // e[9], zp[3] of the staged triangles
   __shared__ uint2 bbox[BIN_CHUNK];
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restri
         // past cn have pref == W and are never selected
         uint32_t lo = 0, hi = BIN_CHUNK;
 #pragma unroll
-        for (int step = 0; step < 9; step++) {  // log2(BIN_CHUNK)
+        for (int step = 0; step < BIN_LOG2; step++) {
           const uint32_t mid = (lo + hi) >> 1;
           const bool le = pref[mid] <= w;
           lo = le ? mid : lo;
@@ -1648,7 +1649,10 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   static const bool no_bins = getenv("RDOOM_NO_BINS") != nullptr;  // debug: exercise the fallback scan
   if (lv->ntri && !no_bins) {
     const uint32_t bin_tiles = std::min<uint32_t>((uint32_t)(tiles_x * tiles_y), MAX_TILES);
-    hipLaunchKernelGGL(bin_kernel, dim3(n), dim3(BIN_THREADS), 2 * sizeof(uint32_t) * bin_tiles, st, b->d_recs,
+    static const int bin_threads = getenv("RDOOM_BIN_THREADS") ? atoi(getenv("RDOOM_BIN_THREADS")) : 256;  // tuning switch
+    auto bk = bin_threads == 512 ? bin_kernel<512, 9> : (bin_threads == 128 ? bin_kernel<128, 7> : bin_kernel<256, 8>);
+    const int bt = bin_threads == 512 ? 512 : (bin_threads == 128 ? 128 : 256);
+    hipLaunchKernelGGL(bk, dim3(n), dim3(bt), 2 * sizeof(uint32_t) * bin_tiles, st, b->d_recs,
                        b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap,
                        b->d_overflow);
   } else {
