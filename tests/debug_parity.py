@@ -1,7 +1,7 @@
 """Debug helper (GPU box): where do HIP and the oracle disagree?"""
 import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import rust_doom_amd as rd
 from oracle import raster, wad_oracle

@@ -6,7 +6,7 @@ oracle, the product's C++ builder and the HIP renderer against them.
 The reference (cristicbz/rust-doom) cannot be built or run here (no rustc, no GL) and ships no golden
 vectors for this path, so these digests pin OUR restatement against regressions, not the reference binary.
 
-    python tools/make_golden.py        # rewrites the fixtures
+    python tests/golden/make_golden.py        # rewrites the fixtures
 """
 import hashlib
 import json
@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 

@@ -1,4 +1,4 @@
-"""Committed golden fixtures (tests/golden/digests.json + poses.npy, generator tools/make_golden.py):
+"""Committed golden fixtures (tests/golden/digests.json + poses.npy, generator tests/golden/make_golden.py):
 sha256 of every level array of the nine synthetic levels and of 27 oracle-rendered frames (palette-index
 framebuffer + winning primitive ids).  Checked against (a) the oracle itself (regression pin), (b) the
 product's C++ loader/builder, (c, GPU) the HIP renderer."""
