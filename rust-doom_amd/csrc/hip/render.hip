@@ -1097,12 +1097,27 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
         const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
         const uint32_t base2 = base * 2u;  // byte offsets < 2^27: one 32-bit VGPR offset from the uniform base pointer
         const char *tb = reinterpret_cast<const char *>(lv.texels);
-        // Certificate for integer (non-power-of-two) tile sizes, evaluated only in waves that hold such a record:
-        // with guard = 2^-20 * max(|x|, y), guard <= r <= y - guard and |x| < 2^23 imply that no integer lies between
-        // x * RN(1/y) and RN(x / y) and that y * floor is exact (fastmath.hpp).  Power-of-two axes always pass.
+        // Certificate for integer (non-power-of-two) tile sizes, evaluated only in waves that hold such a record
+        // (fastmath.hpp, mod_cert): with guard >= 2^-20 * max(|x|, y), guard <= r <= y - guard and |x| < 2^23 imply that
+        // no integer lies between x * RN(1/y) and RN(x / y) and that y * floor is exact.  One guard per run and axis:
+        // |x_k| = |n_k * w_k| <= max(|n_first|, |n_last|) * max(w_first, w_last) because the numerator plane n and, for
+        // rw > 0, w = 1/rw are monotone along the run (and rounding is monotone).  The run's guard is at least every
+        // pixel's own guard, so passing here implies mod_cert() for each pixel -- the form the on-device self-test sweeps.
+        // Power-of-two axes always pass.
         const bool any_np2 = __any((flags & SHADE_NP2) != 0u);
         const bool p2x = (flags & SHADE_POW2_X) != 0u, p2y = (flags & SHADE_POW2_Y) != 0u;
         bool mod_ok = true;
+        float lox = 0.0f, hix = 0.0f, loy = 0.0f, hiy = 0.0f;
+        if (any_np2) {
+          const float pxl = px0 + (float)(NPX - 1);
+          const f32x2 w_ends = exact_rcp2(f32x2{fmaf(wa, px0, row_w), fmaf(wa, pxl, row_w)});
+          const float w_hi = fmaxf(w_ends.x, w_ends.y);
+          const float bu = fmaxf(fabsf(fmaf(ua, px0, row_u)), fabsf(fmaf(ua, pxl, row_u))) * w_hi;
+          const float bv = fmaxf(fabsf(fmaf(va, px0, row_v)), fabsf(fmaf(va, pxl, row_v))) * w_hi;
+          lox = fmaxf(bu, size_x) * 0x1p-20f, hix = size_x - lox;
+          loy = fmaxf(bv, size_y) * 0x1p-20f, hiy = size_y - loy;
+          mod_ok = (p2x | (bu < 0x1p23f)) & (p2y | (bv < 0x1p23f));
+        }
         f32x2 ww[NP];
         uint32_t texel[NPX], any_texel = 0;
         float rw_first = 0.0f, rw_last = 0.0f;
@@ -1122,8 +1137,8 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
           fh = f32x2{floorf(fh.x), floorf(fh.y)};
           const f32x2 ry = pk_fma(splat(-size_y), fh, tv);
           if (any_np2)
-            mod_ok = mod_ok & mod_cert(tu.x, rx.x, size_x, p2x) & mod_cert(tu.y, rx.y, size_x, p2x) &
-                     mod_cert(tv.x, ry.x, size_y, p2y) & mod_cert(tv.y, ry.y, size_y, p2y);
+            mod_ok = mod_ok & (p2x | ((rx.x >= lox) & (rx.x <= hix) & (rx.y >= lox) & (rx.y <= hix))) &
+                     (p2y | ((ry.x >= loy) & (ry.x <= hiy) & (ry.y >= loy) & (ry.y <= hiy)));
           const f32x2 ux = rx + splat(atlas_u), uy = ry + splat(atlas_v);  // F3
           const uint32_t o0 = (((uint32_t)cvt_floor_i32(uy.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.x) & wm);
           const uint32_t o1 = (((uint32_t)cvt_floor_i32(uy.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.y) & wm);
