@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 OUT = os.path.join(HERE, 'librdoom_hip.so')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 COMMON = ['-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '-I' + os.path.join(ROOT, 'include'),
-          '-Wall', '-Wno-unused-function', '-Wno-bitwise-instead-of-logical']  # '          '-Wall', '-Wno-unused-function']' on bools is deliberate: branch-free
+          '-Wall', '-Wno-unused-function', '-Wno-bitwise-instead-of-logical']  # bitwise and on bools is deliberate (branch-free)
 
 
 def sources():
