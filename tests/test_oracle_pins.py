@@ -2,6 +2,7 @@
 this path: `test_wad_name` (wad/src/name.rs:163-190).  Its 15 asserts are reproduced verbatim here and run
 against BOTH the numpy oracle (oracle/wad_oracle.py:wad_name) and the product's C++ implementation behind the
 C ABI (rdoom_wad_name_from_bytes).  Everything else on the path is unpinned by the reference."""
+import numpy as np
 import pytest
 
 import rust_doom_amd as rd
@@ -42,3 +43,107 @@ def test_wad_name_uppercases():
     """from_bytes upper-cases ASCII letters (name.rs:50) -- not in the reference test, follows from the source."""
     assert wad_oracle.wad_name(b'sky1') == b'SKY1\0\0\0\0' == rd.wad_name(b'sky1')
     assert wad_oracle.wad_name(b'f_sky1') == b'F_SKY1\0\0' == rd.wad_name(b'f_sky1')
+
+
+# The reference's other test on this path, `test_wad_metadata` (wad/src/meta.rs:261-358): its inline TOML fixture,
+# reproduced verbatim; the reference only asserts that it parses.  Here: it parses in the oracle and in the product's
+# C++ reader, and the oracle's view of it has the shape the fixture spells out.
+META_FIXTURE = '''
+            [[sky]]
+                level_pattern = "MAP(0[1-9]|10|11)"
+                texture_name = "SKY1"
+                tiled_band_size = 0.15
+            [[sky]]
+                level_pattern = "MAP(1[2-9]|20)"
+                texture_name = "SKY2"
+                tiled_band_size = 0.15
+            [[sky]]
+                level_pattern = "MAP(2[1-9]|32)"
+                texture_name = "SKY3"
+                tiled_band_size = 0.15
+            [animations]
+                flats = [
+                    ["NUKAGE1", "NUKAGE2", "NUKAGE3"],
+                    [],
+                ]
+                walls = [
+                    [],
+                    ["DBRAIN1", "DBRAIN2", "DBRAIN3",  "DBRAIN4"],
+                ]
+            [things]
+                [[things.decorations]]
+                    thing_type = 10
+                    radius = 16
+                    sprite = "PLAY"
+                    sequence = "W"
+                    obstacle = false
+                    hanging = false
+
+                [[things.decorations]]
+                    thing_type = 12
+                    radius = 8
+                    sprite = "PLAY"
+                    sequence = "W"
+                    obstacle = false
+                    hanging = false
+
+                [[things.weapons]]
+                    # BFG 9000
+                    thing_type = 2006
+                    radius = 20
+                    sprite = "BFUG"
+                    sequence = "A"
+                    hanging = false
+
+                [[things.artifacts]]
+                    # Computer map
+                    thing_type = 2026
+                    radius = 20
+                    sprite = "PMAP"
+                    sequence = "ABCDCB"
+                    hanging = false
+
+                [[things.ammo]]
+                    # Box of ammo
+                    thing_type = 2048
+                    radius = 20
+                    sprite = "AMMO"
+                    sequence = "A"
+                    hanging = false
+
+                [[things.powerups]]
+                    # Backpack
+                    thing_type = 8
+                    radius = 20
+                    sprite = "BPAK"
+                    sequence = "A"
+                    hanging = false
+
+                [[things.keys]]
+                    # Red keycard
+                    thing_type = 13
+                    radius = 20
+                    sprite = "RKEY"
+                    sequence = "AB"
+                    hanging = false
+
+                [[things.monsters]]
+                    # Baron of Hell
+                    thing_type = 3003
+                    radius = 24
+                    sprite = "BOSS"
+                    sequence = "A"
+                    hanging = false
+'''
+
+
+def test_wad_metadata_fixture_parses(tmp_path, wad_path):
+    path = tmp_path / 'meta_fixture.toml'
+    path.write_text(META_FIXTURE)
+    meta = wad_oracle.Metadata(str(path))
+    assert [s['texture_name'].rstrip(b'\0') for s in meta.sky] == [b'SKY1', b'SKY2', b'SKY3']
+    assert all(s['tiled_band_size'] == np.float32(0.15) for s in meta.sky)
+    assert [len(a) for a in meta.anim_flats] == [3, 0] and [len(a) for a in meta.anim_walls] == [0, 4]
+    assert [t['thing_type'] for t in meta.things] == [10, 12, 2006, 8, 2026, 2048, 13, 3003]  # category order of meta.rs:173-206
+    assert meta.find_thing(2026)['sequence'] == 'ABCDCB' and meta.linedef == {}
+    rd.Wad(wad_path, str(path))  # Archive::open -> WadMetadata::from_file: must parse
