@@ -256,7 +256,7 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
           sr.wp[2] = rr.wp[2];
           sr.atlas_u = au;
           sr.atlas_v = av;
-          sr.size_x = tri.size_x;
+          sr.size_x = kind == RDOOM_KIND_SKY ? 4.0f * au / 3.14159265358f : tri.size_x;  // sky: the u shift of sky.frag:15
           sr.size_y = tri.size_y;
           sr.light = (float)pc.lights[(tri.packed >> 8) & 0xFFu] / 255.0f;
           const uint32_t bx = __float_as_uint(tri.size_x), by = __float_as_uint(tri.size_y);
@@ -980,9 +980,10 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
                                                        const uint32_t *__restrict__ vis, uint32_t n_poses,
                                                        uint32_t chunks_per_pose, uint32_t quads_per_pose,
                                                        uint32_t quads_per_row, uint32_t div_m, uint32_t div_sh,
-                                                       int width, int height, uint8_t *__restrict__ fb,
-                                                       uint32_t *__restrict__ fix_count, uint2 *__restrict__ fix_list,
-                                                       uint32_t fix_cap, uint32_t debug_leak_mod) {
+                                                       int width, int height, const float *__restrict__ ndc_tab,
+                                                       uint8_t *__restrict__ fb, uint32_t *__restrict__ fix_count,
+                                                       uint2 *__restrict__ fix_list, uint32_t fix_cap,
+                                                       uint32_t debug_leak_mod) {
   constexpr int NP = 2 * NQ, NPX = 4 * NQ;  // float2 pairs and pixels per lane
   __shared__ uint8_t cmap[32 * 256];
   __shared__ uint32_t wlist[4][FRAG_WLIST];
@@ -1174,6 +1175,36 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
           }
           done = true;
         }
+      } else if ((flags & 3u) == RDOOM_KIND_SKY) {
+        // a run of sky (sky.frag:12-26): the colour depends on the pixel and the pose only.  ndc_tab holds
+        // p / (size / 2) - 1 for every column and row of the frame (computed once per batch with the same two
+        // operations), the record carries v_r.y and 4 v_r.x / 3.14159265358; the row part is evaluated once per run.
+        const uint32_t row = fast_div(q0, div_m, div_sh), qx = q0 - row * quads_per_row;
+        const float ushift = __uint_as_float(r2.w), vr1 = __uint_as_float(r2.z), band = lv.sky_band;
+        float uvy = (-ndc_tab[(uint32_t)width + row] + 1.0f) + vr1;
+        if (uvy < 0.0f) {
+          uvy = fabsf(glsl_mod(-uvy + band, band * 2.0f) - band);
+        } else if (uvy >= 2.0f) {
+          uvy = fabsf(glsl_mod((uvy - 2.0f) + band, band * 2.0f) - band);
+        } else if (uvy >= 1.0f) {
+          uvy = 1.0f - uvy;
+        }
+        const float fy = uvy - floorf(uvy);
+        int iy = (int)floorf(fy * (float)lv.sky_h);
+        if (iy >= (int)lv.sky_h) iy = (int)lv.sky_h - 1;
+        const uint16_t *srow = lv.sky_tex + (size_t)iy * lv.sky_w;
+        uint32_t c[NPX];
+#pragma unroll
+        for (int k = 0; k < NPX; k++) {
+          const float uvx = ndc_tab[qx * 4u + (uint32_t)k] - ushift;
+          const float fx = uvx - floorf(uvx);
+          int ix = (int)floorf(fx * (float)lv.sky_w);
+          if (ix >= (int)lv.sky_w) ix = (int)lv.sky_w - 1;
+          c[k] = cmap[srow[ix] & 0xFFu];
+        }
+#pragma unroll
+        for (int k = 0; k < NPX; k++) out[k >> 2] |= c[k] << (8 * (k & 3));
+        done = true;
       }
     }
     if (done & valid) {
@@ -1342,6 +1373,7 @@ struct rdoom_batch {
   hipEvent_t ev_copy = nullptr;  // H2D of h_poses finished: staging may be rewritten
   bool want_prim = false;
   bool vis16 = false;  // record indices fit 16 bits: visibility words are u16
+  float *d_ndc = nullptr;  // (ix + 0.5) / (width / 2) - 1 for every column, then (iy + 0.5) / (height / 2) - 1 for every row
 };
 
 extern "C" {
@@ -1556,6 +1588,7 @@ void rdoom_batch_destroy(rdoom_batch *b) {
   if (b->ev_copy) (void)hipEventDestroy(b->ev_copy);
   if (b->h_poses) (void)hipHostFree(b->h_poses);
   if (b->h_objects) (void)hipHostFree(b->h_objects);
+  if (b->d_ndc) (void)hipFree(b->d_ndc);
   if (b->d_objects) (void)hipFree(b->d_objects);
   delete b;
 }
@@ -1590,6 +1623,13 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, sizeof(uint32_t) * npx);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
+  if (e == hipSuccess) {  // sky.frag:13's ndc per column / row, same two operations as the per-pixel form
+    std::vector<float> ndc(width + height);
+    for (uint32_t i = 0; i < width; i++) ndc[i] = ((float)i + 0.5f) / (0.5f * (float)width) - 1.0f;
+    for (uint32_t i = 0; i < height; i++) ndc[width + i] = ((float)i + 0.5f) / (0.5f * (float)height) - 1.0f;
+    e = hipMalloc((void **)&b->d_ndc, sizeof(float) * ndc.size());
+    if (e == hipSuccess) e = hipMemcpy(b->d_ndc, ndc.data(), sizeof(float) * ndc.size(), hipMemcpyHostToDevice);
+  }
   for (auto &ev : b->ev)
     if (e == hipSuccess) e = hipEventCreate(&ev);
   if (e == hipSuccess) e = hipEventCreate(&b->ev_copy);
@@ -1733,8 +1773,8 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   if (frag_dbg == 2) frag = b->vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>;
 
   hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv->view, b->d_recs, b->cap, b->d_poses,
-                     b->d_vis, n, fblocks, qpp, qpr, div_m, div_sh, W, H, b->d_fb, b->d_fix_count, b->d_fix_list,
-                     b->fix_cap, debug_leak_mod);
+                     b->d_vis, n, fblocks, qpp, qpr, div_m, div_sh, W, H, b->d_ndc, b->d_fb, b->d_fix_count,
+                     b->d_fix_list, b->fix_cap, debug_leak_mod);
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap,
                      b->d_poses, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow,
                      b->d_fix_count, b->d_fix_list, b->fix_cap, b->d_vis, b->vis16 ? 1u : 0u,

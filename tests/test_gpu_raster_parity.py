@@ -199,3 +199,34 @@ def test_edge_cases(oracle_levels):
     small.render(p, lights)
     want = raster.RasterOracle(lvl).render(p[0]['modelview'], p[0]['projection'], 0.0, lights, 8, 1)
     assert np.array_equal(small.read_framebuffer()[0], want)
+
+
+def test_sky_heavy_views(oracle_levels):
+    """looking up from the sub-sectors under open sky: long runs of sky pixels (the fragment kernel's sky-run path,
+    sky.frag:12-26 incl. the mirrored / tiled bands above the texture)"""
+    lv = oracle_levels(0)
+    w, h = 320, 200
+    sky_verts = np.asarray(lv.sky_vertices, np.float32).reshape(-1, 3)
+    assert len(sky_verts) > 0
+    rng = np.random.RandomState(3)
+    poses = np.zeros(20, rd.POSE)
+    for i in range(len(poses)):
+        c = sky_verts[rng.randint(len(sky_verts))]
+        eye = np.array([c[0] + rng.uniform(-0.5, 0.5), 0.45 + rng.uniform(0, 0.3), c[2] + rng.uniform(-0.5, 0.5)])
+        poses[i]['modelview'] = view_matrix(eye, rng.uniform(0, 2 * np.pi), rng.uniform(0.3, 1.3))
+        poses[i]['projection'] = reference_projection(w, h)
+    lights = lv.lights.fill_buffer_at(0.0)
+    batch = rd.Batch(rd.DeviceLevel(lv), w, h, len(poses))
+    batch.enable_primitive_ids()
+    batch.render(poses, lights)
+    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    ro = raster.RasterOracle(lv)
+    first = np.cumsum([0] + [int(d[3]) // 3 for d in lv.draws])
+    sky_px = 0
+    for i in range(len(poses)):
+        ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], 0.0, lights, w, h, want_prim=True)
+        assert np.array_equal(oprim, prim[i]) and np.array_equal(ofb, fb[i]), i
+        for di, d in enumerate(lv.draws):
+            if d[0] == rd.KIND_SKY:
+                sky_px += int(((oprim >= first[di]) & (oprim < first[di + 1])).sum())
+    assert sky_px > 0.1 * len(poses) * w * h, sky_px
