@@ -230,3 +230,24 @@ def test_sky_heavy_views(oracle_levels):
             if d[0] == rd.KIND_SKY:
                 sky_px += int(((oprim >= first[di]) & (oprim < first[di + 1])).sum())
     assert sky_px > 0.1 * len(poses) * w * h, sky_px
+
+
+def test_explicit_stream(oracle_levels):
+    """rdoom_batch_render on a caller-provided hipStream_t == on the default stream"""
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    side = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(side)) == 0
+    lv = oracle_levels(1)
+    w, h, n = 128, 80, 4
+    poses = sweep_poses(lv, n, w, h, seed=9)
+    lights = lv.lights.fill_buffer_at(0.0)
+    batch = rd.Batch(rd.DeviceLevel(lv), w, h, n)
+    batch.render(poses, lights)
+    want = batch.read_framebuffer()
+    batch.render(poses[::-1].copy(), lights, stream=side.value)  # different content in between
+    assert hip.hipStreamSynchronize(side) == 0
+    batch.render(poses, lights, stream=side.value)
+    assert hip.hipStreamSynchronize(side) == 0
+    assert np.array_equal(batch.read_framebuffer(), want)
+    assert hip.hipStreamDestroy(side) == 0
