@@ -901,24 +901,25 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
 
 // =================================================================================================
 // Kernel 3: fragment kernel (F1..F6): visibility record -> atlas texel -> COLORMAP row -> 8-bit
-// palette index.  One lane per 4 horizontally adjacent pixels: one 16-byte visibility load, one
-// 4-byte packed store; COLORMAP (8 KiB) is staged in LDS once per workgroup, which walks
-// FRAG_CHUNK consecutive 1024-pixel slabs of one pose (all blocks of a pose run on one XCD).
+// palette index.  One lane per run of 8 (or 4) horizontally adjacent pixels: one 16-byte visibility
+// load, one 8-byte packed store; COLORMAP (8 KiB) is staged in LDS once per workgroup, which walks
+// FRAG_CHUNK consecutive slabs of one pose (all blocks of a pose run on one XCD).
 //
-// Packed path (96 % of the quads of an E1M1 sweep): the four pixels see the same flat/wall triangle
-// with power-of-two tile sizes.  Its 64-byte shade record is loaded once and the four pixels are
-// shaded branch-free in two float2 halves (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 evaluate the
-// same IEEE operations as their scalar forms, lane by lane).  Exactness devices, all verified or proven:
-//   * 1/rw        = rcp, fma, fma       -- equals the correctly rounded quotient for EVERY binary32 rw with
-//   * 0.9/(d+0.9) = rcp, mul, fma, fma     2^-100 <= |x| <= 2^100 (exhaustive sweep on gfx950,
-//                                          tools/fastmath_exhaustive.hip, and the -m gpu self-test)
+// Packed path (96 % of the runs of an E1M1 sweep): the pixels of the run see the same flat/wall triangle
+// whose tile sizes are powers of two or integers.  Its 64-byte shade record is loaded once and the pixels
+// are shaded branch-free two at a time (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 evaluate the same IEEE
+// operations as their scalar forms, half by half).  Exactness devices, all verified or proven
+// (fastmath.hpp; rdoom_selftest_fastmath sweeps them on the device, tests/test_gpu_fastmath.py):
+//   * 1/rw        = rcp, fma, fma       -- equals the correctly rounded quotient for EVERY binary32 x with
+//   * 0.9/(d+0.9) = rcp, mul, fma, fma     2^-100 <= |x| <= 2^100 (exhaustive sweep on gfx950)
 //   * mod by a power of two: x / 2^k == x * 2^-k, and y * floor(q) is exact, so fma(-y, f, x) == x - y * f
-//   * COLORMAP row: every operation of F1/F4/F5 is monotone and rw is monotone along the quad, so when the
-//     rows of the two end pixels agree the two middle pixels have that row too
-//   * mod by an integer tile size: floor(t * RN(1/size)) is certified per pixel by a remainder test (see F2)
-// A quad that fails any precondition (mixed triangles, sky, rw outside the verified range, an uncertified
-// mod, a transparent texel) is appended to an LDS list and shaded afterwards
-// by the general per-pixel body, lane per pixel -- same results, one code path for everything unusual.
+//   * mod by an integer tile size: floor(t * RN(1/size)) is certified by a remainder test (see F2)
+//   * COLORMAP row: every operation of F1/F4/F5 is monotone and rw is monotone along the run, so when the
+//     rows of the two end pixels agree every pixel between them has that row too
+// A run of sky is shaded from per-batch ndc tables.  A run that fails any precondition (mixed triangles,
+// decor, rw outside the verified range, an uncertified mod, a transparent texel) is appended, quad by quad,
+// to a per-wave LDS list and shaded afterwards by the general per-pixel body, lane per pixel -- same
+// results, one code path for everything unusual.
 // =================================================================================================
 constexpr int FRAG_CHUNK = 16;
 constexpr int FRAG_WLIST = 160;  // per-wave list of unfinished quads: at most 15 carried over + 64 x 2 new
