@@ -11,6 +11,13 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once, exactly as
+    # __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU; about two minutes)
+    lib = os.path.join(ROOT, 'rust-doom_amd', 'librdoom_hip.so')
+    oracle_so = os.path.join(ROOT, 'oracle', '_build', 'liboracle_raster.so')
+    if not (os.path.exists(lib) and os.path.exists(oracle_so)):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope='session')
