@@ -979,7 +979,8 @@ template <int NQ, int DBG, bool VIS16>  // NQ: adjacent quads per lane (1 or 2; 
 __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
                                                        const uint32_t *__restrict__ vis, uint32_t n_poses,
-                                                       uint32_t chunks_per_pose, uint32_t quads_per_pose,
+                                                       uint32_t chunks_per_pose, uint32_t chunk_iters,
+                                                       uint32_t quads_per_pose,
                                                        uint32_t quads_per_row, uint32_t div_m, uint32_t div_sh,
                                                        int width, int height, const float *__restrict__ ndc_tab,
                                                        uint8_t *__restrict__ fb, uint32_t *__restrict__ fix_count,
@@ -1039,8 +1040,8 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
     }
   };
   const uint32_t units_per_pose = quads_per_pose / (uint32_t)NQ;  // a unit = the NQ adjacent quads of one lane
-  for (int it = 0; it < FRAG_CHUNK; it++) {
-    const uint32_t ui = (chunk * FRAG_CHUNK + (uint32_t)it) * 256u + threadIdx.x;
+  for (uint32_t it = 0; it < chunk_iters; it++) {
+    const uint32_t ui = (chunk * chunk_iters + it) * 256u + threadIdx.x;
     if (ui - lane >= units_per_pose) break;  // wave-uniform: the whole wave is past the end of the frame
     const bool valid = ui < units_per_pose;
     const uint32_t q0 = ui * (uint32_t)NQ;
@@ -1765,7 +1766,8 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   static const int frag_dbg = getenv("RDOOM_FRAG_DBG") ? atoi(getenv("RDOOM_FRAG_DBG")) : 0;  // timing experiments (wrong images)
   const int nq = (frag_nq_env == 2 && W % 8 == 0) ? 2 : 1;  // quads per lane: two when rows divide into 8-pixel runs
   const uint32_t units = qpp / (uint32_t)nq;
-  const uint32_t fblocks = (units + FRAG_CHUNK * 256 - 1) / (FRAG_CHUNK * 256);
+  static const uint32_t frag_chunk = getenv("RDOOM_FRAG_CHUNK") ? (uint32_t)std::max(1, atoi(getenv("RDOOM_FRAG_CHUNK"))) : (uint32_t)FRAG_CHUNK;  // tuning switch
+  const uint32_t fblocks = (units + frag_chunk * 256 - 1) / (frag_chunk * 256);
   HIP_TRY(hipMemsetAsync(b->d_fix_count, 0, 2 * sizeof(uint32_t), st));
   const uint64_t fgrid = (uint64_t)((n + 7) / 8) * 8ull * fblocks;
   if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
@@ -1774,7 +1776,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   if (frag_dbg == 2) frag = b->vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>;
 
   hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv->view, b->d_recs, b->cap, b->d_poses,
-                     b->d_vis, n, fblocks, qpp, qpr, div_m, div_sh, W, H, b->d_ndc, b->d_fb, b->d_fix_count,
+                     b->d_vis, n, fblocks, frag_chunk, qpp, qpr, div_m, div_sh, W, H, b->d_ndc, b->d_fb, b->d_fix_count,
                      b->d_fix_list, b->fix_cap, debug_leak_mod);
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap,
                      b->d_poses, W, H, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow,
