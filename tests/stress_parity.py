@@ -1,6 +1,6 @@
 """One-off randomized stress (GPU box): every synthetic level x random poses / times / resolutions / object offsets,
 HIP vs oracle, framebuffers and winning primitives.  Not collected by pytest; run as
-    python tests/stress_parity.py [poses_per_level] [seed]
+    python tests/stress_parity.py [poses_per_level] [seed] [width height]
 Prints one line per level and exits non-zero on any mismatch."""
 import os
 import sys
@@ -20,6 +20,8 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.RandomState(seed)
     sizes = [(640, 400), (324, 180), (1280, 720), (200, 120)]
+    if len(sys.argv) > 4:  # one frame size for every level, e.g. 1920 1080
+        sizes = [(int(sys.argv[3]), int(sys.argv[4]))]
     total_bad = 0
     for index in range(9):
         lv = wad_oracle.build_level(ensure_wad(), META_PATH, index)
