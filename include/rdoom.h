@@ -175,7 +175,9 @@ rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out);
 rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **out_device_ptr);
 /* glReadPixels analogue: synchronises, copies frames [first, first+count) to host memory */
 rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *batch, uint32_t first, uint32_t count, uint8_t *host_out);
-/* winning primitive id per pixel (global triangle index in draw order, 0xFFFFFFFF = none) */
+/* Debug / test facility: capture the winning primitive id per pixel (global triangle index in draw order,
+ * 0xFFFFFFFF = none) on the following renders, then read it back.  No GL counterpart. */
+rdoom_status rdoom_batch_enable_primitive_ids(rdoom_batch *batch);
 rdoom_status rdoom_batch_read_primitive_ids(rdoom_batch *batch, uint32_t first, uint32_t count, uint32_t *host_out);
 
 /* On-device verification of the exact short forms the fragment kernel uses instead of IEEE division

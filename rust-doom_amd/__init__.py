@@ -76,7 +76,7 @@ API_SYMBOLS = [
     'rdoom_wad_open', 'rdoom_wad_close', 'rdoom_wad_num_levels', 'rdoom_wad_level_name',
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
     'rdoom_built_counters', 'rdoom_built_lights_at', 'rdoom_built_start', 'rdoom_built_floor_centroids',
-    'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_batch_render_objects', 'rdoom_level_num_objects']
+    'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_batch_render_objects', 'rdoom_level_num_objects', 'rdoom_batch_enable_primitive_ids']
 
 _lib = None
 
@@ -362,9 +362,7 @@ class Batch:
         return out
 
     def enable_primitive_ids(self):
-        tmp = np.zeros(1, np.uint32)
-        st = lib().rdoom_batch_read_primitive_ids(self._h, 0, 0, tmp.ctypes.data_as(ctypes.c_void_p))
-        return st
+        _check(lib().rdoom_batch_enable_primitive_ids(self._h))
 
     def read_primitive_ids(self, first=0, count=None):
         count = self.last_n - first if count is None else count

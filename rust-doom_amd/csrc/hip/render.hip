@@ -1848,15 +1848,21 @@ rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *b, uint32_t first, uint32
   return RDOOM_OK;
 }
 
+rdoom_status rdoom_batch_enable_primitive_ids(rdoom_batch *b) {
+  if (!b) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  if (!b->d_prim) {
+    const size_t npx = (size_t)b->width * b->height * b->max_poses;
+    HIP_TRY(hipMalloc((void **)&b->d_prim, sizeof(uint32_t) * npx));
+  }
+  b->want_prim = true;
+  b->last_n = 0;  // nothing captured yet: render first
+  return RDOOM_OK;
+}
+
 rdoom_status rdoom_batch_read_primitive_ids(rdoom_batch *b, uint32_t first, uint32_t count, uint32_t *host_out) {
   if (!b || !host_out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
-  if (!b->want_prim || !b->d_prim) {
-    // enable capture lazily; the caller must render again
-    const size_t npx = (size_t)b->width * b->height * b->max_poses;
-    if (!b->d_prim) HIP_TRY(hipMalloc((void **)&b->d_prim, sizeof(uint32_t) * npx));
-    b->want_prim = true;
-    return rdoom::fail(RDOOM_BAD_ARG, "primitive-id capture enabled now; render again, then read");
-  }
+  if (!b->want_prim || !b->d_prim)
+    return rdoom::fail(RDOOM_BAD_ARG, "primitive ids are not captured: call rdoom_batch_enable_primitive_ids, then render");
   if ((uint64_t)first + count > b->last_n) return rdoom::fail(RDOOM_BAD_ARG, "frame range outside the last render");
   const size_t frame = (size_t)b->width * b->height;
   HIP_TRY(hipDeviceSynchronize());
