@@ -35,7 +35,7 @@ def build(force=False, verbose=False):
     headers = glob.glob(os.path.join(HERE, 'csrc', '**', '*.hpp'), recursive=True) + \
         glob.glob(os.path.join(ROOT, 'include', '*.h')) + [os.path.abspath(__file__)]
     os.makedirs(OBJ, exist_ok=True)
-    objs = []
+    objs, jobs = [], []
     for src in hip + cpp:
         obj = os.path.join(OBJ, os.path.basename(src) + '.o')
         objs.append(obj)
@@ -44,9 +44,17 @@ def build(force=False, verbose=False):
                 cmd = [hipcc, '--offload-arch=gfx950', '-x', 'hip'] + COMMON + ['-c', src, '-o', obj]
             else:
                 cmd = [hipcc, '-x', 'c++'] + COMMON + ['-c', src, '-o', obj]
+            jobs.append(cmd)
+    if jobs:  # one translation unit per kernel: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(' '.join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+
+        with ThreadPoolExecutor(min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(OUT, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
         if verbose:

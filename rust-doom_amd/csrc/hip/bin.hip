@@ -1,0 +1,175 @@
+// Kernel 1b: binning of the near-to-far record list into per-tile lists.
+//
+// Part of the pose-batch renderer for gfx950 (MI355X) that replaces the reference's GL draw path:
+// assets/shaders/static.{vert,frag}, sky.{vert,frag}, sprite.{vert,frag} and the fixed-function state of
+// engine/src/renderer.rs:49-57 + engine/src/window.rs:12,40-44.  The arithmetic is specified in DESIGN.md
+// "Raster arithmetic"; operation order follows that text, not the oracle's source.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rdoom_dev {
+namespace {
+
+// =================================================================================================
+// Kernel 1b: binning.  One workgroup per pose turns the near-to-far record list into
+// per-tile lists: count -> scan -> fill.  The unit of work is a (triangle, tile of its bbox) pair: the
+// raster coefficients of BIN_CHUNK triangles are staged in LDS together with an exclusive prefix sum of
+// their bbox tile counts, and every lane finds its pair by binary search in that prefix -- lanes stay busy
+// whatever the mix of one-tile and whole-frame triangles, and the exact tile/quadrant test runs from LDS.
+// entry = record index | quadrant mask << 28.  Pairs are visited in list order one workgroup-full at a time, so a tile's
+// list is near-to-far up to that window; the rasteriser re-sorts each list chunk by record index (= depth
+// rank).  Order only affects early-z efficiency: the winner is order-independent.  If a pose needs more than
+// entry_cap entries (or the frame has more than MAX_TILES tiles) its overflow flag is set and the
+// rasteriser scans the sorted list instead.
+// =================================================================================================
+
+template <int BIN_THREADS, int BIN_LOG2>  // threads per workgroup = triangles staged per round (one per thread)
+__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restrict__ recs,
+                                                          const uint4 *__restrict__ sorted,
+                                                          const uint32_t *__restrict__ counts, uint32_t cap,
+                                                          int tiles_x, int tiles_y, uint2 *__restrict__ tile_hdr,
+                                                          uint32_t *__restrict__ entries, uint32_t entry_cap,
+                                                          uint32_t *__restrict__ overflow) {
+  constexpr uint32_t BIN_CHUNK = BIN_THREADS;
+  static_assert((1 << BIN_LOG2) == BIN_THREADS, "bin_kernel: BIN_LOG2");
+  extern __shared__ uint32_t bin_dyn[];  // tile_cnt[T], tile_off[T]
+  __shared__ uint4 coef[BIN_CHUNK][3];   // e[9], zp[3] of the staged triangles
+  __shared__ uint2 bbox[BIN_CHUNK];
+  __shared__ uint32_t trange[BIN_CHUNK];  // tile rectangle to visit: tx0 | ty0 << 8 | width << 16
+  __shared__ uint32_t pref[BIN_CHUNK + 1];
+  __shared__ uint32_t scan_tmp[BIN_THREADS];
+  const uint32_t pose = blockIdx.x;
+  const int tid = threadIdx.x;
+  const uint32_t T = (uint32_t)(tiles_x * tiles_y);
+  if (T > MAX_TILES) {
+    if (tid == 0) overflow[pose] = 1u;
+    return;
+  }
+  uint32_t *tile_cnt = bin_dyn, *tile_off = bin_dyn + T;
+  const TriRec *prec = recs + (size_t)pose * cap;
+  const uint4 *psorted = sorted + (size_t)pose * cap;
+  uint2 *hdr = tile_hdr + (size_t)pose * T;
+  uint32_t *pent = entries + (size_t)pose * entry_cap;
+  const uint32_t n = counts[pose];
+  for (uint32_t i = tid; i < T; i += BIN_THREADS) tile_cnt[i] = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    for (uint32_t cbase = 0; cbase < n; cbase += BIN_CHUNK) {
+      const uint32_t cn = min(BIN_CHUNK, n - cbase);
+      __syncthreads();  // previous round's readers of coef/pref are done (and tile_cnt / tile_off are ready)
+      uint32_t nt = 0;
+      if ((uint32_t)tid < cn) {
+        const uint4 ent = psorted[cbase + tid];  // (bb0, bb1, record index == cbase + tid, depth bucket)
+        const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[cbase + tid]);
+        const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2];
+        coef[tid][0] = c0;
+        coef[tid][1] = c1;
+        coef[tid][2] = c2;
+        bbox[tid] = make_uint2(ent.x, ent.y);
+        int tx0 = (int)((ent.x & 0xFFFFu) >> 6), ty0 = (int)((ent.x >> 16) >> 6), tx1 = (int)((ent.y & 0xFFFFu) >> 6),
+            ty1 = (int)((ent.y >> 16) >> 6);
+        if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 32) {
+          // a big tile rectangle (typically a triangle that crosses the eye plane: bbox = whole frame, S6): shrink
+          // it to the tile rows / columns whose full-width / full-height strip can be touched at all.  Exact
+          // (rect_may_touch is conservative and hierarchical), so no tile that passes the per-tile test is lost.
+          const float fx0 = (float)(tx0 * 64) + 0.5f, fx1 = (float)(tx1 * 64) + 63.5f;
+          const float fy0 = (float)(ty0 * 64) + 0.5f, fy1 = (float)(ty1 * 64) + 63.5f;
+          while (ty0 <= ty1 && !rect_may_touch(c0, c1, c2, fx0, fx1, (float)(ty0 * 64) + 0.5f, (float)(ty0 * 64) + 63.5f)) ty0++;
+          while (ty1 >= ty0 && !rect_may_touch(c0, c1, c2, fx0, fx1, (float)(ty1 * 64) + 0.5f, (float)(ty1 * 64) + 63.5f)) ty1--;
+          while (tx0 <= tx1 && !rect_may_touch(c0, c1, c2, (float)(tx0 * 64) + 0.5f, (float)(tx0 * 64) + 63.5f, fy0, fy1)) tx0++;
+          while (tx1 >= tx0 && !rect_may_touch(c0, c1, c2, (float)(tx1 * 64) + 0.5f, (float)(tx1 * 64) + 63.5f, fy0, fy1)) tx1--;
+        }
+        nt = (tx1 >= tx0 && ty1 >= ty0) ? (uint32_t)((tx1 - tx0 + 1) * (ty1 - ty0 + 1)) : 0u;
+        trange[tid] = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)(tx1 - tx0 + 1) << 16);  // tiles per side <= 128
+      }
+      scan_tmp[tid] = nt;
+      __syncthreads();
+      for (int d = 1; d < BIN_THREADS; d <<= 1) {
+        const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
+        __syncthreads();
+        scan_tmp[tid] += v;
+        __syncthreads();
+      }
+      pref[tid] = scan_tmp[tid] - nt;  // exclusive; entries past cn repeat the total
+      const uint32_t W = scan_tmp[BIN_THREADS - 1];
+      if (tid == 0) pref[BIN_CHUNK] = W;
+      __syncthreads();
+      for (uint32_t w = (uint32_t)tid; w < W; w += BIN_THREADS) {
+        // largest i with pref[i] <= w (pref non-decreasing, pref[0] = 0, pref[BIN_CHUNK] = W > w); triangles
+        // past cn have pref == W and are never selected
+        uint32_t lo = 0, hi = BIN_CHUNK;
+#pragma unroll
+        for (int step = 0; step < BIN_LOG2; step++) {
+          const uint32_t mid = (lo + hi) >> 1;
+          const bool le = pref[mid] <= w;
+          lo = le ? mid : lo;
+          hi = le ? hi : mid;
+        }
+        const uint32_t t = w - pref[lo];
+        const uint2 bb = bbox[lo];
+        const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
+        const uint32_t tr = trange[lo];
+        const int tx0 = (int)(tr & 0xFFu), ty0 = (int)((tr >> 8) & 0xFFu), ntx = (int)(tr >> 16);
+        const int ty = (int)(((float)t + 0.5f) / (float)ntx), tx = (int)t - ty * ntx;  // t / ntx (t < 8192: exact)
+        const uint4 c0 = coef[lo][0], c1 = coef[lo][1], c2 = coef[lo][2];
+        uint32_t qm = 0;
+        if (tile_may_touch(c0, c1, c2, (tx0 + tx) * 64, (ty0 + ty) * 64))
+          qm = tile_quadrant_mask(c0, c1, c2, x0, y0, x1, y1, (tx0 + tx) * 64, (ty0 + ty) * 64);
+        if (qm) {
+          const uint32_t tile = (uint32_t)((ty0 + ty) * tiles_x + tx0 + tx);
+          if (pass == 0) {
+            atomicAdd(&tile_cnt[tile], 1u);
+          } else {
+            const uint32_t pos = atomicAdd(&tile_off[tile], 1u);
+            if (pos < entry_cap) pent[pos] = (cbase + lo) | (qm << 28);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (pass == 1) break;
+    // exclusive scan of tile_cnt -> tile_off (thread t owns T/512 consecutive tiles); headers out
+    const uint32_t per = (T + BIN_THREADS - 1u) / BIN_THREADS, lo = min((uint32_t)tid * per, T), hi = min(lo + per, T);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += tile_cnt[i];
+    scan_tmp[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < BIN_THREADS; d <<= 1) {
+      const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
+      __syncthreads();
+      scan_tmp[tid] += v;
+      __syncthreads();
+    }
+    const uint32_t total = scan_tmp[BIN_THREADS - 1];
+    uint32_t run = scan_tmp[tid] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+      tile_off[i] = run;
+      hdr[i] = make_uint2(run, tile_cnt[i]);
+      run += tile_cnt[i];
+    }
+    if (tid == 0) overflow[pose] = total > entry_cap ? 1u : 0u;
+    if (total > entry_cap) return;  // uniform
+  }
+}
+
+}  // namespace
+
+void launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
+                uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
+                uint32_t *overflow) {
+  const uint32_t bin_tiles = std::min<uint32_t>((uint32_t)(tiles_x * tiles_y), MAX_TILES);
+  static const int bin_threads = getenv("RDOOM_BIN_THREADS") ? atoi(getenv("RDOOM_BIN_THREADS")) : 256;  // tuning switch
+  auto bk = bin_threads == 512 ? bin_kernel<512, 9> : (bin_threads == 128 ? bin_kernel<128, 7> : bin_kernel<256, 8>);
+  const int bt = bin_threads == 512 ? 512 : (bin_threads == 128 ? 128 : 256);
+  hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bt), 2 * sizeof(uint32_t) * bin_tiles, st, recs, sorted, counts, cap, tiles_x,
+                     tiles_y, tile_hdr, entries, entry_cap, overflow);
+}
+
+}  // namespace rdoom_dev

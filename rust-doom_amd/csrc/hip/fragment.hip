@@ -1,0 +1,496 @@
+// Kernels 3 + 4: fragment kernel (visibility -> palette index) and the alpha-leak fixup.
+//
+// Part of the pose-batch renderer for gfx950 (MI355X) that replaces the reference's GL draw path:
+// assets/shaders/static.{vert,frag}, sky.{vert,frag}, sprite.{vert,frag} and the fixed-function state of
+// engine/src/renderer.rs:49-57 + engine/src/window.rs:12,40-44.  The arithmetic is specified in DESIGN.md
+// "Raster arithmetic"; operation order follows that text, not the oracle's source.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rdoom_dev {
+namespace {
+
+// =================================================================================================
+// Kernel 3: fragment kernel (F1..F6): visibility record -> atlas texel -> COLORMAP row -> 8-bit
+// palette index.  One lane per run of 8 (or 4) horizontally adjacent pixels: one 16-byte visibility
+// load, one 8-byte packed store; COLORMAP (8 KiB) is staged in LDS once per workgroup, which walks
+// FRAG_CHUNK consecutive slabs of one pose (all blocks of a pose run on one XCD).
+//
+// Packed path (96 % of the runs of an E1M1 sweep): the pixels of the run see the same flat/wall triangle
+// whose tile sizes are powers of two or integers.  Its 64-byte shade record is loaded once and the pixels
+// are shaded branch-free two at a time (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 evaluate the same IEEE
+// operations as their scalar forms, half by half).  Exactness devices, all verified or proven
+// (fastmath.hpp; rdoom_selftest_fastmath sweeps them on the device, tests/test_gpu_fastmath.py):
+//   * 1/rw        = rcp, fma, fma       -- equals the correctly rounded quotient for EVERY binary32 x with
+//   * 0.9/(d+0.9) = rcp, mul, fma, fma     2^-100 <= |x| <= 2^100 (exhaustive sweep on gfx950)
+//   * mod by a power of two: x / 2^k == x * 2^-k, and y * floor(q) is exact, so fma(-y, f, x) == x - y * f
+//   * mod by an integer tile size: floor(t * RN(1/size)) is certified by a remainder test (see F2)
+//   * COLORMAP row: every operation of F1/F4/F5 is monotone and rw is monotone along the run, so when the
+//     rows of the two end pixels agree every pixel between them has that row too
+// A run of sky is shaded from per-batch ndc tables.  A run that fails any precondition (mixed triangles,
+// decor, rw outside the verified range, an uncertified mod, a transparent texel) is appended, quad by quad,
+// to a per-wave LDS list and shaded afterwards by the general per-pixel body, lane per pixel -- same
+// results, one code path for everything unusual.
+// =================================================================================================
+constexpr int FRAG_CHUNK = 16;
+constexpr int FRAG_WLIST = 160;  // per-wave list of unfinished quads: at most 15 carried over + 64 x 2 new
+
+__device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const uint8_t *cmap, float px, float py,
+                                              int width, int height, float vr0, float vr1) {
+  const float ndc_x = px / (0.5f * (float)width) - 1.0f;
+  const float ndc_y = py / (0.5f * (float)height) - 1.0f;
+  float uvx = ndc_x;
+  float uvy = -ndc_y;
+  uvx = uvx - 4.0f * vr0 / 3.14159265358f;
+  uvy = (uvy + 1.0f) + vr1;
+  const float band = lv.sky_band;
+  if (uvy < 0.0f) {
+    uvy = fabsf(glsl_mod(-uvy + band, band * 2.0f) - band);
+  } else if (uvy >= 2.0f) {
+    uvy = fabsf(glsl_mod((uvy - 2.0f) + band, band * 2.0f) - band);
+  } else if (uvy >= 1.0f) {
+    uvy = 1.0f - uvy;
+  }
+  const float fx = uvx - floorf(uvx), fy = uvy - floorf(uvy);
+  int ix = (int)floorf(fx * (float)lv.sky_w), iy = (int)floorf(fy * (float)lv.sky_h);
+  if (ix >= (int)lv.sky_w) ix = (int)lv.sky_w - 1;
+  if (iy >= (int)lv.sky_h) iy = (int)lv.sky_h - 1;
+  const uint32_t texel = lv.sky_tex[(size_t)iy * lv.sky_w + (size_t)ix];
+  return cmap[texel & 0xFFu];
+}
+
+// returns the palette index, or 0x100 | index when the winning wall fragment's texel is transparent (the
+// rasteriser treated a border-masked texture as opaque and the coordinate leaked onto the ring)
+__device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const uint8_t *cmap, const ShadeRec &s,
+                                                float px, float py, float row_w, float row_u, float row_v,
+                                                int width, int height, const PoseConst &pc) {
+  const uint32_t kind = s.flags & 3u;
+  if (kind == RDOOM_KIND_SKY) return shade_sky(lv, cmap, px, py, width, height, s.atlas_u, s.atlas_v);
+  const TexelAt t = texel_coords(s, px, row_w, row_u, row_v);
+  const uint32_t texel = load_texel(lv, s, t.ix, t.iy);
+  if (kind != RDOOM_KIND_FLAT && (texel & 0x8000u)) return 0x100u;
+  float light;
+  if (kind == RDOOM_KIND_DECOR) {  // sprite.frag:22-25: DIST_SCALE = 1, light = min(v_light, 2 v_light - dist_term)
+    const float dist_term = fminf(1.0f, 1.0f - 1.0f / (t.dist + 1.0f));
+    light = fminf(s.light, s.light * 2.0f - dist_term);
+  } else {
+    const float dist_term = fminf(1.0f, 1.0f - 0.9f / (t.dist + 0.9f));
+    light = s.light * 2.0f - dist_term;
+  }
+  const float tt = (1.0f - light) * 32.0f;
+  const int rowc = tt < 0.0f ? 0 : (tt >= 32.0f ? 31 : (int)floorf(tt));
+  return cmap[rowc * 256 + (int)(texel & 0xFFu)];
+}
+
+template <int NQ, int DBG, bool VIS16>  // NQ: adjacent quads per lane (1 or 2; the frame width is a multiple of 4 NQ);
+                                        // DBG: timing experiments only; VIS16: 16-bit visibility words (0xFFFF = none)
+__global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+                                                       uint32_t cap, const PoseConst *__restrict__ poses,
+                                                       const uint32_t *__restrict__ vis, uint32_t n_poses,
+                                                       uint32_t chunks_per_pose, uint32_t chunk_iters,
+                                                       uint32_t quads_per_pose,
+                                                       uint32_t quads_per_row, uint32_t div_m, uint32_t div_sh,
+                                                       int width, int height, const float *__restrict__ ndc_tab,
+                                                       uint8_t *__restrict__ fb, uint32_t *__restrict__ fix_count,
+                                                       uint2 *__restrict__ fix_list, uint32_t fix_cap,
+                                                       uint32_t debug_leak_mod) {
+  constexpr int NP = 2 * NQ, NPX = 4 * NQ;  // float2 pairs and pixels per lane
+  __shared__ uint8_t cmap[32 * 256];
+  __shared__ uint32_t wlist[4][FRAG_WLIST];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(lv.colormap);
+    uint4 *dst = reinterpret_cast<uint4 *>(cmap);
+    dst[threadIdx.x] = src[threadIdx.x];
+    dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+  }
+  __syncthreads();
+  // blockIdx -> (pose, chunk): all chunks of a pose on one XCD (b % 8), like the rasteriser
+  const uint32_t g = blockIdx.x >> 3;
+  const uint32_t pose = (g / chunks_per_pose) * 8u + (blockIdx.x & 7u);
+  const uint32_t chunk = g % chunks_per_pose;
+  if (pose >= n_poses) return;
+  const TriRec *prec = recs + (size_t)pose * cap;
+  constexpr uint32_t NONE_ID = VIS16 ? 0xFFFFu : NONE;
+  const uint32_t *pvis32 = vis + (size_t)pose * quads_per_pose * 4u;
+  const uint16_t *pvis16 = reinterpret_cast<const uint16_t *>(vis) + (size_t)pose * quads_per_pose * 4u;
+  uint32_t *pfb = reinterpret_cast<uint32_t *>(fb) + (size_t)pose * quads_per_pose;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t *mylist = wlist[threadIdx.x >> 6];
+  uint32_t wn = 0;  // wave-uniform: quads waiting in mylist
+  const PoseConst &pc = poses[pose];
+  // general body: 16 listed quads at a time, lane per pixel.  The list is private to the wave (LDS operations of
+  // one wave execute in order), so no workgroup barrier is involved and waves never wait for each other.
+  auto shade_listed = [&](uint32_t first, uint32_t count) {
+    const uint32_t j = lane >> 2, k = lane & 3u;
+    if (j < count) {
+      const uint32_t qi = mylist[first + j];
+      const uint32_t row = fast_div(qi, div_m, div_sh), qx = qi - row * quads_per_row;
+      const uint32_t id = VIS16 ? (uint32_t)pvis16[(size_t)qi * 4u + k] : pvis32[(size_t)qi * 4u + k];
+      uint32_t c = 0;
+      const uint32_t pix = (row * quads_per_row + qx) * 4u + k;
+      if (id != NONE_ID) {
+        const ShadeRec cur = prec[id].s;
+        const float py = (float)row + 0.5f, px = (float)(qx * 4u + k) + 0.5f;
+        c = shade_pixel(lv, cmap, cur, px, py, fmaf(cur.wp[1], py, cur.wp[2]), fmaf(cur.up[1], py, cur.up[2]),
+                        fmaf(cur.vp[1], py, cur.vp[2]), width, height, pc);
+        // debug_leak_mod != 0 (tests only): pretend every n-th pixel leaked, so fixup_kernel's general rule
+        // is exercised on ordinary pixels too -- the output must not change
+        const bool forced = debug_leak_mod != 0u && pix % debug_leak_mod == 0u;
+        if ((c & 0x100u) || forced) {  // rare: alpha leak, queue the pixel for exact re-resolution
+          const uint32_t slot = atomicAdd(fix_count, 1u);
+          if (slot < fix_cap) fix_list[slot] = make_uint2(pose, pix);
+        }
+      }
+      uint32_t v = (c & 0xFFu) << (8u * k);
+      v |= __shfl_xor(v, 1);
+      v |= __shfl_xor(v, 2);
+      if (k == 0) pfb[qi] = v;
+    }
+  };
+  const uint32_t units_per_pose = quads_per_pose / (uint32_t)NQ;  // a unit = the NQ adjacent quads of one lane
+  for (uint32_t it = 0; it < chunk_iters; it++) {
+    const uint32_t ui = (chunk * chunk_iters + it) * 256u + threadIdx.x;
+    if (ui - lane >= units_per_pose) break;  // wave-uniform: the whole wave is past the end of the frame
+    const bool valid = ui < units_per_pose;
+    const uint32_t q0 = ui * (uint32_t)NQ;
+    // visibility words of my NPX pixels
+    uint32_t id[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; k++) id[k] = NONE_ID;
+    if (valid) {
+      if (VIS16) {
+        if (NQ == 2) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(pvis16 + (size_t)q0 * 4u);
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < NPX; k++) id[k] = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu);
+        } else {
+          const uint2 v = *reinterpret_cast<const uint2 *>(pvis16 + (size_t)q0 * 4u);
+          id[0] = v.x & 0xFFFFu, id[1] = v.x >> 16, id[2] = v.y & 0xFFFFu, id[3] = v.y >> 16;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(pvis32 + ((size_t)q0 + (size_t)q) * 4u);
+          id[4 * q] = v.x, id[4 * q + 1] = v.y, id[4 * q + 2] = v.z, id[4 * q + 3] = v.w;
+        }
+      }
+    }
+    bool uniform = true;
+#pragma unroll
+    for (int k = 1; k < NPX; k++) uniform &= id[k] == id[0];
+    bool done = false;
+    uint32_t out[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) out[q] = 0;
+    if (uniform & (id[0] == NONE_ID)) done = true;  // background (or past the end: nothing is stored)
+    if (uniform & (id[0] != NONE_ID) & (debug_leak_mod == 0u)) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[id[0]].s);
+      const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+      const uint32_t flags = r3.z, tex = r3.w;
+      // (all four loads are issued before the flag is examined: one memory latency, not two)
+      asm volatile("" ::"v"(r0.x), "v"(r1.x), "v"(r2.x));
+      if (flags & SHADE_FAST) {
+        const float wa = __uint_as_float(r0.x), wb = __uint_as_float(r0.y), wc = __uint_as_float(r0.z),
+                    ua = __uint_as_float(r0.w), ub = __uint_as_float(r1.x), uc = __uint_as_float(r1.y),
+                    va = __uint_as_float(r1.z), vb = __uint_as_float(r1.w), vc = __uint_as_float(r2.x),
+                    atlas_u = __uint_as_float(r2.y), atlas_v = __uint_as_float(r2.z), size_x = __uint_as_float(r2.w),
+                    size_y = __uint_as_float(r3.x), light = __uint_as_float(r3.y);
+        const uint32_t row = fast_div(q0, div_m, div_sh), qx = q0 - row * quads_per_row;
+        const float py = (float)row + 0.5f;
+        const float px0 = (float)(qx * 4u) + 0.5f;
+        const float row_w = fmaf(wb, py, wc), row_u = fmaf(ub, py, uc), row_v = fmaf(vb, py, vc);
+        // F2 preparation: q0 = t * RN(1/size) equals the quotient exactly for a power-of-two size; for an integer
+        // size it is within |t/size| * 2^-23 of it, and the remainder test below certifies
+        // floor(q0) == floor(RN(t / size)) (else the run goes to the general body).
+        const f32x2 inv_s = exact_rcp2(f32x2{size_x, size_y});
+        // F3 parameters: one u16 texel store, REPEAT = masks
+        const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
+        const uint32_t base2 = base * 2u;  // byte offsets < 2^27: one 32-bit VGPR offset from the uniform base pointer
+        const char *tb = reinterpret_cast<const char *>(lv.texels);
+        // Certificate for integer (non-power-of-two) tile sizes, evaluated only in waves that hold such a record
+        // (fastmath.hpp, mod_cert): with guard >= 2^-20 * max(|x|, y), guard <= r <= y - guard and |x| < 2^23 imply that
+        // no integer lies between x * RN(1/y) and RN(x / y) and that y * floor is exact.  One guard per run and axis:
+        // |x_k| = |n_k * w_k| <= max(|n_first|, |n_last|) * max(w_first, w_last) because the numerator plane n and, for
+        // rw > 0, w = 1/rw are monotone along the run (and rounding is monotone).  The run's guard is at least every
+        // pixel's own guard, so passing here implies mod_cert() for each pixel -- the form the on-device self-test sweeps.
+        // Power-of-two axes always pass.
+        const bool any_np2 = __any((flags & SHADE_NP2) != 0u);
+        const bool p2x = (flags & SHADE_POW2_X) != 0u, p2y = (flags & SHADE_POW2_Y) != 0u;
+        bool mod_ok = true;
+        float lox = 0.0f, hix = 0.0f, loy = 0.0f, hiy = 0.0f;
+        if (any_np2) {
+          const float pxl = px0 + (float)(NPX - 1);
+          const f32x2 w_ends = exact_rcp2(f32x2{fmaf(wa, px0, row_w), fmaf(wa, pxl, row_w)});
+          const float w_hi = fmaxf(w_ends.x, w_ends.y);
+          const float bu = fmaxf(fabsf(fmaf(ua, px0, row_u)), fabsf(fmaf(ua, pxl, row_u))) * w_hi;
+          const float bv = fmaxf(fabsf(fmaf(va, px0, row_v)), fabsf(fmaf(va, pxl, row_v))) * w_hi;
+          lox = fmaxf(bu, size_x) * 0x1p-20f, hix = size_x - lox;
+          loy = fmaxf(bv, size_y) * 0x1p-20f, hiy = size_y - loy;
+          mod_ok = (p2x | (bu < 0x1p23f)) & (p2y | (bv < 0x1p23f));
+        }
+        f32x2 ww[NP];
+        uint32_t texel[NPX], any_texel = 0;
+        float rw_first = 0.0f, rw_last = 0.0f;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {  // one pair of pixels at a time, straight through to its two texel loads
+          const f32x2 px = {px0 + (float)(2 * p), px0 + (float)(2 * p + 1)};
+          const f32x2 rw = pk_fma(splat(wa), px, splat(row_w));  // F1
+          if (p == 0) rw_first = rw.x;
+          if (p == NP - 1) rw_last = rw.y;
+          ww[p] = exact_rcp2(rw);
+          const f32x2 tu = pk_fma(splat(ua), px, splat(row_u)) * ww[p];
+          const f32x2 tv = pk_fma(splat(va), px, splat(row_v)) * ww[p];
+          f32x2 fq = tu * splat(inv_s.x);  // F2: mod(t, size) = t - size * floor(t / size)
+          fq = f32x2{floorf(fq.x), floorf(fq.y)};
+          const f32x2 rx = pk_fma(splat(-size_x), fq, tu);
+          f32x2 fh = tv * splat(inv_s.y);
+          fh = f32x2{floorf(fh.x), floorf(fh.y)};
+          const f32x2 ry = pk_fma(splat(-size_y), fh, tv);
+          if (any_np2)
+            mod_ok = mod_ok & (p2x | ((rx.x >= lox) & (rx.x <= hix) & (rx.y >= lox) & (rx.y <= hix))) &
+                     (p2y | ((ry.x >= loy) & (ry.x <= hiy) & (ry.y >= loy) & (ry.y <= hiy)));
+          const f32x2 ux = rx + splat(atlas_u), uy = ry + splat(atlas_v);  // F3
+          const uint32_t o0 = (((uint32_t)cvt_floor_i32(uy.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.x) & wm);
+          const uint32_t o1 = (((uint32_t)cvt_floor_i32(uy.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.y) & wm);
+          texel[2 * p] = (DBG & 2) ? (o0 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o0 * 2u + base2));
+          texel[2 * p + 1] = (DBG & 2) ? (o1 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o1 * 2u + base2));
+        }
+        // rw is monotone along the run: both ends inside the verified range of the exact reciprocal forms
+        const bool in_range = (fminf(rw_first, rw_last) >= 0x1p-100f) & (fmaxf(rw_first, rw_last) <= 0x1p100f);
+#pragma unroll
+        for (int k = 0; k < NPX; k++) any_texel |= texel[k];
+        // F4, F5 at the two end pixels; the pixels between them only when the ends disagree
+        auto rows_of = [&](f32x2 dist) {
+          const f32x2 dterm = splat(1.0f) - exact_div09_2(dist + splat(0.9f));
+          const f32x2 lgt = splat(light * 2.0f) - f32x2{fminf(1.0f, dterm.x), fminf(1.0f, dterm.y)};
+          const f32x2 tt = (splat(1.0f) - lgt) * splat(32.0f);
+          return f32x2{fminf(fmaxf(floorf(tt.x), 0.0f), 31.0f), fminf(fmaxf(floorf(tt.y), 0.0f), 31.0f)};
+        };
+        const f32x2 rf_ends = rows_of(f32x2{ww[0].x, ww[NP - 1].y});
+        f32x2 rf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) rf[p] = splat(rf_ends.x);
+        if (rf_ends.x != rf_ends.y) {
+#pragma unroll
+          for (int p = 0; p < NP; p++) rf[p] = rows_of(ww[p]);
+        }
+        const bool opaque = (any_texel & 0x8000u) == 0u;
+        if (in_range & mod_ok & opaque) {
+#pragma unroll
+          for (int p = 0; p < NP; p++) {
+            const uint32_t c0 = cmap[((uint32_t)(int)rf[p].x << 8) | (texel[2 * p] & 0xFFu)],
+                           c1 = cmap[((uint32_t)(int)rf[p].y << 8) | (texel[2 * p + 1] & 0xFFu)];
+            out[p >> 1] |= (c0 | (c1 << 8)) << (16 * (p & 1));
+          }
+          done = true;
+        }
+      } else if ((flags & 3u) == RDOOM_KIND_SKY) {
+        // a run of sky (sky.frag:12-26): the colour depends on the pixel and the pose only.  ndc_tab holds
+        // p / (size / 2) - 1 for every column and row of the frame (computed once per batch with the same two
+        // operations), the record carries v_r.y and 4 v_r.x / 3.14159265358; the row part is evaluated once per run.
+        const uint32_t row = fast_div(q0, div_m, div_sh), qx = q0 - row * quads_per_row;
+        const float ushift = __uint_as_float(r2.w), vr1 = __uint_as_float(r2.z), band = lv.sky_band;
+        float uvy = (-ndc_tab[(uint32_t)width + row] + 1.0f) + vr1;
+        if (uvy < 0.0f) {
+          uvy = fabsf(glsl_mod(-uvy + band, band * 2.0f) - band);
+        } else if (uvy >= 2.0f) {
+          uvy = fabsf(glsl_mod((uvy - 2.0f) + band, band * 2.0f) - band);
+        } else if (uvy >= 1.0f) {
+          uvy = 1.0f - uvy;
+        }
+        const float fy = uvy - floorf(uvy);
+        int iy = (int)floorf(fy * (float)lv.sky_h);
+        if (iy >= (int)lv.sky_h) iy = (int)lv.sky_h - 1;
+        const uint16_t *srow = lv.sky_tex + (size_t)iy * lv.sky_w;
+        uint32_t c[NPX];
+#pragma unroll
+        for (int k = 0; k < NPX; k++) {
+          const float uvx = ndc_tab[qx * 4u + (uint32_t)k] - ushift;
+          const float fx = uvx - floorf(uvx);
+          int ix = (int)floorf(fx * (float)lv.sky_w);
+          if (ix >= (int)lv.sky_w) ix = (int)lv.sky_w - 1;
+          c[k] = cmap[srow[ix] & 0xFFu];
+        }
+#pragma unroll
+        for (int k = 0; k < NPX; k++) out[k >> 2] |= c[k] << (8 * (k & 3));
+        done = true;
+      }
+    }
+    if (done & valid) {
+      if (NQ == 2)
+        *reinterpret_cast<uint2 *>(pfb + q0) = make_uint2(out[0], out[NQ - 1]);
+      else
+        pfb[q0] = out[0];
+    }
+    const unsigned long long sm = __ballot(!done);
+    if (sm) {  // ordered append of this wave's unfinished quads, then shade full groups of 16
+      if (!done) {
+        const uint32_t at = wn + (uint32_t)NQ * (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int q = 0; q < NQ; q++) mylist[at + (uint32_t)q] = q0 + (uint32_t)q;
+      }
+      wn += (uint32_t)NQ * (uint32_t)__popcll(sm);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      while (wn >= 16u) {
+        wn -= 16u;
+        shade_listed(wn, 16u);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (wn) shade_listed(0u, wn);
+}
+
+// =================================================================================================
+// Kernel 4: fixup.  Re-resolves the (rare) pixels queued by the fragment kernel with the general rule
+// R1..R6 applied to every candidate of the pixel's tile: lanes = candidates, lexicographic wave-min of
+// (d24, primitive), then the winner is shaded.  One wave per queued pixel; the list is usually empty.
+// =================================================================================================
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_xor(v, d);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+                                                    const uint4 *__restrict__ sorted,
+                                                    const uint32_t *__restrict__ counts, uint32_t cap,
+                                                    const PoseConst *__restrict__ poses, int width, int height,
+                                                    int tiles_x, int tiles_y, const uint2 *__restrict__ tile_hdr,
+                                                    const uint32_t *__restrict__ entries, uint32_t entry_cap,
+                                                    const uint32_t *__restrict__ overflow,
+                                                    const uint32_t *__restrict__ fix_count,
+                                                    const uint2 *__restrict__ fix_list, uint32_t fix_cap,
+                                                    uint32_t *__restrict__ vis, uint32_t vis16,
+                                                    uint32_t *__restrict__ prim_out, uint8_t *__restrict__ fb,
+                                                    uint32_t *__restrict__ error_flag) {
+  const uint32_t total = *fix_count;
+  if (total > fix_cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *error_flag = 1u;
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave_id = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+  for (uint32_t item = wave_id; item < total; item += n_waves) {
+    const uint2 it = fix_list[item];
+    const uint32_t pose = it.x, pix = it.y;
+    const int iy = (int)(pix / (uint32_t)width), ix = (int)(pix - (uint32_t)iy * (uint32_t)width);
+    const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
+    const TriRec *prec = recs + (size_t)pose * cap;
+    const bool binned = overflow[pose] == 0u;
+    const uint32_t T = (uint32_t)(tiles_x * tiles_y), tile = (uint32_t)((iy >> 6) * tiles_x + (ix >> 6));
+    const uint2 hdr = binned ? tile_hdr[(size_t)pose * T + tile] : make_uint2(0u, counts[pose]);
+    unsigned long long best = ~0ull;
+    uint32_t best_rec = NONE;
+    for (uint32_t base = 0; base < hdr.y; base += 64u) {
+      const uint32_t e = base + lane;
+      unsigned long long key = ~0ull;
+      uint32_t rec = NONE;
+      if (e < hdr.y) {
+        rec = binned ? (entries[(size_t)pose * entry_cap + hdr.x + e] & 0x0FFFFFFFu) : sorted[(size_t)pose * cap + e].z;
+        const RasterRec r = prec[rec].r;
+        const int x0 = (int)(r.bb0 & 0xFFFFu), y0 = (int)(r.bb0 >> 16), x1 = (int)(r.bb1 & 0xFFFFu),
+                  y1 = (int)(r.bb1 >> 16);
+        const float e0 = fmaf(r.e[0], px, fmaf(r.e[1], py, r.e[2])), e1 = fmaf(r.e[3], px, fmaf(r.e[4], py, r.e[5])),
+                    e2 = fmaf(r.e[6], px, fmaf(r.e[7], py, r.e[8]));
+        const bool in0 = (e0 > 0.0f) | ((e0 == 0.0f) & ((r.flags & (1u << 24)) != 0u));
+        const bool in1 = (e1 > 0.0f) | ((e1 == 0.0f) & ((r.flags & (1u << 25)) != 0u));
+        const bool in2 = (e2 > 0.0f) | ((e2 == 0.0f) & ((r.flags & (1u << 26)) != 0u));
+        const float zw = fmaf(r.zp[0], px, fmaf(r.zp[1], py, r.zp[2]));
+        const float rw = fmaf(r.wp[0], px, fmaf(r.wp[1], py, r.wp[2]));
+        bool pass = (ix >= x0) & (ix <= x1) & (iy >= y0) & (iy <= y1) & in0 & in1 & in2 & (zw >= 0.0f) & (zw <= 1.0f) &
+                    (rw > 0.0f);
+        if (pass && (r.flags & RASTER_MASKED_ANY) != 0u) {
+          const ShadeRec sh = prec[rec].s;
+          const TexelAt t = texel_coords(sh, px, fmaf(sh.wp[1], py, sh.wp[2]), fmaf(sh.up[1], py, sh.up[2]),
+                                         fmaf(sh.vp[1], py, sh.vp[2]));
+          pass = (load_texel(lv, sh, t.ix, t.iy) & 0x8000u) == 0u;
+        }
+        if (pass) {
+          const uint32_t d24 = __float2uint_rz(fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f));
+          key = ((unsigned long long)d24 << 32) | (unsigned long long)(r.flags & 0xFFFFFFu);
+        }
+      }
+      const unsigned long long m = wave_min_u64(key);
+      if (m < best) {
+        best = m;
+        const unsigned long long who = __ballot(key == m);
+        best_rec = __shfl(rec, __ffsll((long long)who) - 1);
+      }
+    }
+    if (lane == 0) {
+      const size_t o = ((size_t)pose * (size_t)height + (size_t)iy) * (size_t)width + (size_t)ix;
+      uint32_t colour = 0;
+      if (best_rec != NONE) {
+        const ShadeRec sh = prec[best_rec].s;
+        colour = shade_pixel(lv, lv.colormap, sh, px, py, fmaf(sh.wp[1], py, sh.wp[2]), fmaf(sh.up[1], py, sh.up[2]),
+                             fmaf(sh.vp[1], py, sh.vp[2]), width, height, poses[pose]) & 0xFFu;
+      }
+      if (vis16)
+        reinterpret_cast<uint16_t *>(vis)[o] = (uint16_t)best_rec;  // NONE -> 0xFFFF
+      else
+        vis[o] = best_rec;
+      if (prim_out) prim_out[o] = best_rec == NONE ? NONE : (uint32_t)(best & 0xFFFFFFull);
+      fb[o] = (uint8_t)colour;
+    }
+  }
+}
+
+}  // namespace
+
+rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
+                             const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,
+                             int width, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
+                             const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
+                             bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
+                             uint2 *fix_list, uint32_t fix_cap) {
+  const uint32_t n = n_poses;
+  const int W = width, H = height;
+  const uint32_t qpr = (uint32_t)W / 4u, qpp = qpr * (uint32_t)H;
+  if (qpp >= (1u << 24)) return rdoom::fail(RDOOM_BAD_ARG, "frame too large");
+  // multiply-high divisor for idx / qpr, idx < 2^24 (checked exhaustively at the only places it can fail)
+  if (qpr < 2) return rdoom::fail(RDOOM_BAD_ARG, "width must be at least 8");
+  uint32_t div_sh = 0;
+  while ((2u << div_sh) <= qpr) div_sh++;   // floor(log2(qpr))
+  if ((qpr & (qpr - 1)) == 0) div_sh -= 1;  // power of two: m = 2^31
+  const uint32_t div_m = (uint32_t)((((uint64_t)1 << (32 + div_sh)) + qpr - 1) / qpr);
+  for (uint32_t k = 1; k * qpr <= qpp; k++) {
+    const uint32_t lo = k * qpr - 1, hi = k * qpr;
+    if ((uint32_t)(((uint64_t)lo * div_m) >> 32) >> div_sh != k - 1 ||
+        (hi < qpp && (uint32_t)(((uint64_t)hi * div_m) >> 32) >> div_sh != k))
+      return rdoom::fail(RDOOM_BAD_ARG, "internal: fast_div constants invalid for width %d", W);
+  }
+  static const uint32_t debug_leak_mod = getenv("RDOOM_DEBUG_LEAK_MOD") ? (uint32_t)atoi(getenv("RDOOM_DEBUG_LEAK_MOD")) : 0u;
+  static const int frag_nq_env = getenv("RDOOM_FRAG_NQ") ? atoi(getenv("RDOOM_FRAG_NQ")) : 2;  // tuning switch / tests
+  static const int frag_dbg = getenv("RDOOM_FRAG_DBG") ? atoi(getenv("RDOOM_FRAG_DBG")) : 0;  // timing experiments (wrong images)
+  const int nq = (frag_nq_env == 2 && W % 8 == 0) ? 2 : 1;  // quads per lane: two when rows divide into 8-pixel runs
+  const uint32_t units = qpp / (uint32_t)nq;
+  static const uint32_t frag_chunk =
+      getenv("RDOOM_FRAG_CHUNK") ? (uint32_t)std::max(1, atoi(getenv("RDOOM_FRAG_CHUNK"))) : (uint32_t)FRAG_CHUNK;  // tuning switch
+  const uint32_t fblocks = (units + frag_chunk * 256 - 1) / (frag_chunk * 256);
+  HIP_TRY(hipMemsetAsync(fix_count, 0, 2 * sizeof(uint32_t), st));
+  const uint64_t fgrid = (uint64_t)((n + 7) / 8) * 8ull * fblocks;
+  if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
+  auto frag = nq == 2 ? (vis16 ? fragment_kernel<2, 0, true> : fragment_kernel<2, 0, false>)
+                      : (vis16 ? fragment_kernel<1, 0, true> : fragment_kernel<1, 0, false>);
+  if (frag_dbg == 2) frag = vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>;
+  hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp,
+                     qpr, div_m, div_sh, W, H, ndc_tab, fb, fix_count, fix_list, fix_cap, debug_leak_mod);
+  hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, H, tiles_x, tiles_y,
+                     tile_hdr, entries, entry_cap, overflow, fix_count, fix_list, fix_cap, vis, vis16 ? 1u : 0u, prim_out, fb,
+                     fix_count + 1);
+  return RDOOM_OK;
+}
+
+}  // namespace rdoom_dev

@@ -1,0 +1,39 @@
+// Launchers of the renderer's kernels, one translation unit per kernel (setup.hip, bin.hip, raster.hip,
+// fragment.hip); renderer.hip (the C ABI) strings them together on the caller's stream.
+#pragma once
+#include "records.hpp"
+
+#define HIP_TRY(expr)                                                                                     \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess)                                                                                 \
+      return rdoom::fail(_e == hipErrorOutOfMemory ? RDOOM_OOM : RDOOM_HIP_ERROR, "%s failed: %s", #expr, \
+                         hipGetErrorString(_e));                                                          \
+  } while (0)
+
+namespace rdoom_dev {
+
+constexpr uint32_t MAX_TILES = 8192;     // tiles per frame the binning kernel keeps counters for
+
+// Kernel 1: vertex stage, triangle setup, near-to-far record order (setup.hip)
+void launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
+                  const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
+                  TriRec *recs, TriRec *tmp_recs, uint4 *sorted, uint32_t *counts, uint32_t cap);
+// Kernel 1b: per-tile triangle lists (bin.hip)
+void launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
+                uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
+                uint32_t *overflow);
+// Kernel 2: tiled rasteriser -> visibility words (raster.hip); RDOOM_STATS prints the per-wave census
+rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
+                           const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
+                           int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
+                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out);
+// Kernels 3 + 4: fragment kernel -> palette indices, then the alpha-leak fixup (fragment.hip)
+rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
+                             const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,
+                             int width, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
+                             const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
+                             bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
+                             uint2 *fix_list, uint32_t fix_cap);
+
+}  // namespace rdoom_dev

@@ -1,0 +1,354 @@
+// Kernel 2: tiled rasteriser (wave-autonomous) -> visibility words.
+//
+// Part of the pose-batch renderer for gfx950 (MI355X) that replaces the reference's GL draw path:
+// assets/shaders/static.{vert,frag}, sky.{vert,frag}, sprite.{vert,frag} and the fixed-function state of
+// engine/src/renderer.rs:49-57 + engine/src/window.rs:12,40-44.  The arithmetic is specified in DESIGN.md
+// "Raster arithmetic"; operation order follows that text, not the oracle's source.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rdoom_dev {
+namespace {
+
+// =================================================================================================
+// Rasteriser, per-entry part.  Rejection is hierarchical and exact: fmaf is monotone in each argument, so the
+// extreme of a *computed* edge function, depth plane or 1/w plane over a pixel rectangle sits at a corner --
+// per lane: nearest-corner depth against the lane's farthest pixel (early-z) first, then three edge corners,
+// the depth range and the 1/w plane.  One __any() skips the 16-pixel body when no lane needs it.
+// Winner = lexicographic min of (d24, primitive id): independent of processing order.
+// =================================================================================================
+// One queue entry against one lane's 4x4 block: exact rejection (early-z first), then the pixel bodies (R1..R6).
+// The coefficients arrive wave-uniform (v_readlane broadcasts), i.e. as SGPR operands.
+template <bool STATS, int DBG, class ShadeFetch>
+__device__ __forceinline__ void raster_entry(const DeviceLevelView &lv, const TriRec *__restrict__ prec, float e0a, float e0b,
+                                             float e0c, float e1a, float e1b, float e1c, float e2a, float e2b, float e2c,
+                                             float za, float zb, float zc, float wa, float wb, float wc, int x0, int y0,
+                                             int x1, int y1, uint32_t flags, uint32_t ridx, int bx, int by, float pxlo,
+                                             float pxhi, float pylo, float pyhi, uint32_t (&best_d)[16],
+                                             uint32_t (&best_r)[16], uint32_t &lane_far, ShadeFetch fetch_shade,
+                                             unsigned long long (&st)[16]) {
+    // lane-level exact rejection over my 4x4 block.  Early-z first (most rejected triangles are simply hidden):
+    // nearest depth of the plane over the block against the farthest depth I still hold
+    const float zn = fmaf(za, pos(za) ? pxlo : pxhi, fmaf(zb, pos(zb) ? pylo : pyhi, zc));
+    const uint32_t dn = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
+    const bool zpass = (zn <= 1.0f) & (dn <= lane_far);
+    if (!__any(zpass)) {
+      if (STATS) st[15]++;
+      return;
+    }
+    // largest edge values and farthest depth
+    const float m0 = fmaf(e0a, pos(e0a) ? pxhi : pxlo, fmaf(e0b, pos(e0b) ? pyhi : pylo, e0c));
+    const float m1 = fmaf(e1a, pos(e1a) ? pxhi : pxlo, fmaf(e1b, pos(e1b) ? pyhi : pylo, e1c));
+    const float m2 = fmaf(e2a, pos(e2a) ? pxhi : pxlo, fmaf(e2b, pos(e2b) ? pyhi : pylo, e2c));
+    const float zf = fmaf(za, pos(za) ? pxhi : pxlo, fmaf(zb, pos(zb) ? pyhi : pylo, zc));
+    const bool need0 = zpass && bx <= x1 && bx + 3 >= x0 && by <= y1 && by + 3 >= y0 && m0 >= 0.0f && m1 >= 0.0f &&
+                       m2 >= 0.0f && zf >= 0.0f;
+    if (STATS && !__any(need0)) st[14]++;
+    if (!__any(need0)) return;
+    // R3 needs rw > 0: a block whose largest 1/w is not positive holds no coverable pixel (same corner argument)
+    const float rwf = fmaf(wa, pos(wa) ? pxhi : pxlo, fmaf(wb, pos(wb) ? pyhi : pylo, wc));
+    const bool need = need0 & (rwf > 0.0f);
+    if (!__any(need)) return;
+    if (DBG == 2) {
+      if (need) best_r[0] = ridx;
+      return;
+    }
+    if (STATS) st[2]++, st[3] += (unsigned long long)__popcll(__ballot(need));
+    // Fast path (exact): block fully inside the bbox, whole block inside the depth range and in front
+    // of the eye, texture rectangle fully opaque.  Edge ties and depth ties are only *detected* here and
+    // replayed through the general path below, so the result is the same as running it everywhere.
+    // A texture whose only transparent texels lie in the one-texel ring around its rectangle
+    // (RASTER_MASKED_BORDER) is treated as opaque here; the rare pixel whose float mod lands on the ring
+    // is caught by the fragment kernel (it sees a transparent texel) and re-resolved by fixup_kernel.
+    const float rwn = fmaf(wa, pos(wa) ? pxlo : pxhi, fmaf(wb, pos(wb) ? pylo : pyhi, wc));
+    const bool fast = need & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) & ((flags & RASTER_MASKED_INTERIOR) == 0u);
+    // pixels of my block outside the triangle's bbox (S6) never win: bit k of `outside` (k = 4 * row + column).
+    // need guarantees the block overlaps the bbox, so the column and row ranges below are non-empty.
+    uint32_t outside = 0u;
+    if (__any(fast & !((bx >= x0) & (bx + 3 <= x1) & (by >= y0) & (by + 3 <= y1)))) {
+      const int clo = max(x0 - bx, 0), chi = min(x1 - bx, 3), rlo = max(y0 - by, 0), rhi = min(y1 - by, 3);
+      const uint32_t cm = ((2u << chi) - 1u) & ~((1u << clo) - 1u);                // columns inside, 4 bits
+      const uint32_t rows = ((16u << (4 * rhi)) - 1u) & ~((1u << (4 * rlo)) - 1u);  // all pixels of the rows inside
+      outside = ~((cm * 0x1111u) & rows) & 0xFFFFu;
+    }
+    bool redo = false, updated = false;
+    if (STATS && __any(fast)) st[4]++, st[5] += (unsigned long long)__popcll(__ballot(fast));
+    if (fast) {
+#pragma unroll
+      for (int ry = 0; ry < 4; ry++) {
+        const float py = pylo + (float)ry;
+        const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
+        const float tz = fmaf(zb, py, zc);
+#pragma unroll
+        for (int rx = 0; rx < 4; rx++) {
+          const int k = ry * 4 + rx;
+          const float px = pxlo + (float)rx;
+          const float em = fminf(fminf(fmaf(e0a, px, t0), fmaf(e1a, px, t1)), fmaf(e2a, px, t2));
+          const uint32_t d24 = __float2uint_rz(fmaf(fmaf(za, px, tz), 16777215.0f, 0.5f));
+          const uint32_t d24m = d24 | (uint32_t)__builtin_amdgcn_sbfe((int)outside, k, 1);  // all ones when outside
+          const bool win = (em > 0.0f) & (d24m < best_d[k]);
+          redo |= (em == 0.0f) | ((em > 0.0f) & (d24 == best_d[k]));
+          best_d[k] = win ? d24 : best_d[k];
+          best_r[k] = win ? ridx : best_r[k];
+          updated |= win;
+        }
+      }
+    }
+    if (__any(need & (!fast | redo))) {
+      if (STATS) {
+        st[6]++, st[7] += (unsigned long long)__popcll(__ballot(need & (!fast | redo)));
+        // why: [10] depth range, [11] 1/w <= 0 in the block, [12] masked texture, [13] tie replay
+        st[10] += (unsigned long long)__popcll(__ballot(need & !((zn >= 0.0f) & (zf <= 1.0f))));
+        st[11] += (unsigned long long)__popcll(__ballot(need & !(rwn > 0.0f)));
+        st[12] += (unsigned long long)__popcll(__ballot(need & ((flags & RASTER_MASKED_INTERIOR) != 0u)));
+        st[13] += (unsigned long long)__popcll(__ballot(need & fast & redo));
+      }
+      if (need & (!fast | redo)) {
+        const uint32_t prim = flags & 0xFFFFFFu;
+#pragma unroll
+        for (int ry = 0; ry < 4; ry++) {
+          const int iy = by + ry;
+          const float py = (float)iy + 0.5f;
+          const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
+          const float tz = fmaf(zb, py, zc), tw = fmaf(wb, py, wc);
+          const bool rowin = iy >= y0 && iy <= y1;
+#pragma unroll
+          for (int rx = 0; rx < 4; rx++) {
+            const int ix = bx + rx;
+            const float px = (float)ix + 0.5f;
+            const float e0 = fmaf(e0a, px, t0), e1 = fmaf(e1a, px, t1), e2 = fmaf(e2a, px, t2);
+            const bool in0 = (e0 > 0.0f) | ((e0 == 0.0f) & ((flags & (1u << 24)) != 0u));
+            const bool in1 = (e1 > 0.0f) | ((e1 == 0.0f) & ((flags & (1u << 25)) != 0u));
+            const bool in2 = (e2 > 0.0f) | ((e2 == 0.0f) & ((flags & (1u << 26)) != 0u));
+            const float zw = fmaf(za, px, tz);
+            const float rw = fmaf(wa, px, tw);
+            const uint32_t d24 = __float2uint_rz(fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f));
+            const int k = ry * 4 + rx;
+            const uint32_t bd = best_d[k], br = best_r[k];
+            bool pass = rowin & (ix >= x0) & (ix <= x1) & in0 & in1 & in2 & (zw >= 0.0f) & (zw <= 1.0f) &
+                        (rw > 0.0f) & (d24 <= bd);
+            if (pass && d24 == bd)  // depth tie (rare): the earlier primitive keeps the pixel
+              pass = br == NONE || prim < (prec[br].r.flags & 0xFFFFFFu);
+            if (pass && (flags & RASTER_MASKED_ANY) != 0u) {  // R6: alpha test before the depth write
+              const ShadeRec sh = fetch_shade();
+              const TexelAt t =
+                  texel_coords(sh, px, tw, fmaf(sh.up[1], py, sh.up[2]), fmaf(sh.vp[1], py, sh.vp[2]));
+              // texture rectangle fully opaque: only a coordinate that the float mod pushed just outside
+              // the rectangle can hit a transparent neighbour texel -- fetch only then
+              const bool must_fetch = (flags & RASTER_MASKED_INTERIOR) != 0u || t.ix < (int)sh.atlas_u ||
+                                      t.ix >= (int)(sh.atlas_u + sh.size_x) || t.iy < (int)sh.atlas_v ||
+                                      t.iy >= (int)(sh.atlas_v + sh.size_y);
+              if (must_fetch) pass = (load_texel(lv, sh, t.ix, t.iy) & 0x8000u) == 0u;
+            }
+            if (pass) {
+              best_d[k] = d24;
+              best_r[k] = ridx;
+              updated = true;
+            }
+          }
+        }
+      }
+    }
+    if (updated) {
+      uint32_t m = best_d[0];
+#pragma unroll
+      for (int k = 1; k < 16; k++) m = max(m, best_d[k]);
+      lane_far = m;
+    }
+}
+
+// =================================================================================================
+// Kernel 2: tiled rasteriser, wave-autonomous.  One 256-thread workgroup per (pose, 64x64 tile); each wavefront
+// owns a 32x32 quadrant and runs on its own (no LDS staging of records, no workgroup barriers); each lane owns a
+// 4x4 pixel block whose depth / winner live in registers.  blockIdx -> (pose, tile) keeps all tiles of a pose on
+// one XCD (b % 8): its records stay in that XCD's L2.
+//   * candidates  64 tile-list entries at a time, one per lane; the lanes whose entry touches this wave's
+//                 quadrant are ranked by record index (= depth rank) with readlane broadcasts and compacted
+//                 through a 256-byte per-wave LDS scratch;
+//   * records     lane s gathers the 80-byte raster record of the s-th entry straight into registers and
+//                 computes, for all entries at once, the nearest depth of the triangle over the quadrant;
+//   * walk        entry s is broadcast with v_readlane: its coefficients become wave-uniform SGPR operands.
+//                 One compare against the lanes' farthest depths skips a hidden triangle before anything
+//                 else is touched (most rejections are of this kind).
+// =================================================================================================
+template <bool STATS, int DBG = 0>  // DBG: timing experiments only (1 = no queue walk, 2 = reject tests but no pixel bodies)
+__global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+                                                             const uint4 *__restrict__ sorted,
+                                                             const uint32_t *__restrict__ counts, uint32_t cap,
+                                                             uint32_t n_poses, int width, int height, int tiles_x,
+                                                             int tiles_y, const uint2 *__restrict__ tile_hdr,
+                                                             const uint32_t *__restrict__ entries, uint32_t entry_cap,
+                                                             const uint32_t *__restrict__ overflow,
+                                                             uint32_t *__restrict__ vis, uint32_t vis16,
+                                                             uint32_t *__restrict__ prim_out,
+                                                             unsigned long long *__restrict__ stats) {
+  unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  __shared__ uint32_t wq[4][64];
+  const uint32_t b = blockIdx.x;
+  const uint32_t T = (uint32_t)(tiles_x * tiles_y);
+  const uint32_t g = b >> 3;
+  const uint32_t pose = (g / T) * 8u + (b & 7u);
+  const uint32_t tile = g % T;
+  if (pose >= n_poses) return;
+  const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE_W, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE_H;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int qx0 = tx0 + (wave & 1) * 32, qy0 = ty0 + (wave >> 1) * 32;  // this wave's quadrant
+  const int bx = qx0 + (lane & 7) * 4, by = qy0 + (lane >> 3) * 4;      // this lane's 4x4 block
+  const float pxlo = (float)bx + 0.5f, pxhi = (float)bx + 3.5f, pylo = (float)by + 0.5f, pyhi = (float)by + 3.5f;
+  const float qxl = (float)qx0 + 0.5f, qxh = (float)qx0 + 31.5f, qyl = (float)qy0 + 0.5f, qyh = (float)qy0 + 31.5f;
+  uint32_t best_d[16], best_r[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    best_d[k] = NONE;
+    best_r[k] = NONE;
+  }
+  uint32_t lane_far = NONE;  // max of best_d: the farthest depth this lane still holds
+  const TriRec *prec = recs + (size_t)pose * cap;
+  const uint4 *psorted = sorted + (size_t)pose * cap;
+  const bool binned = overflow[pose] == 0u;  // the pose's per-tile lists are complete
+  const uint2 hdr = binned ? tile_hdr[(size_t)pose * T + tile] : make_uint2(0u, counts[pose]);
+  const uint32_t *pent = entries + (size_t)pose * entry_cap + hdr.x;
+  const uint32_t count = DBG == 1 ? 0u : hdr.y;
+  uint32_t *myq = wq[wave];
+  for (uint32_t base = 0; base < count; base += 64u) {
+    // ---- candidates: one per lane ------------------------------------------------------------------
+    const uint32_t i = base + (uint32_t)lane;
+    uint32_t cand = 0;
+    bool rel = false;
+    if (i < count) {
+      if (binned) {
+        const uint32_t e = pent[i];
+        cand = e & 0x0FFFFFFFu;
+        rel = ((e >> (28 + wave)) & 1u) != 0u;  // exact quadrant test done by the binning kernel
+      } else {
+        // pose without complete bins: every visible triangle is a candidate; bbox, then the exact quadrant test
+        const uint4 bb = psorted[i];  // (bb0, bb1, record index, depth bucket), near to far
+        cand = bb.z;
+        const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
+        if (x0 <= qx0 + 31 && x1 >= qx0 && y0 <= qy0 + 31 && y1 >= qy0) {
+          const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[cand]);
+          rel = rect_may_touch(rp[0], rp[1], rp[2], qxl, qxh, qyl, qyh);
+        }
+      }
+    }
+    if (STATS && !binned) st[8] += (unsigned long long)__popcll(__ballot(i < count)), st[9] += (unsigned long long)__popcll(__ballot(rel));
+    const unsigned long long rm = __ballot(rel);
+    const uint32_t n = (uint32_t)__popcll(rm);
+    if (n == 0u) continue;
+    // rank of my entry among the relevant ones (record index = depth rank; the lists are near-sorted already)
+    uint32_t rank = 0;
+    for (unsigned long long m = rm; m; m &= m - 1ull) {
+      const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(m));
+      rank += kj < cand ? 1u : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier readers of myq are done
+    if (rel) myq[rank] = cand;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- records: lane s holds entry s ---------------------------------------------------------------
+    const bool have = (uint32_t)lane < n;
+    const uint32_t myrec = have ? myq[lane] : 0u;
+    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0, c4 = c0;
+    if (have) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[myrec]);
+      c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3], c4 = rp[4];
+    }
+    // nearest depth of my entry's plane over the quadrant (exact corner argument), as d24; none if beyond far
+    uint32_t dnq = NONE;
+    {
+      const float za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
+      const float zn = fmaf(za, za > 0.0f ? qxl : qxh, fmaf(zb, zb > 0.0f ? qyl : qyh, zc));
+      if (have && zn <= 1.0f) dnq = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
+    }
+    // ---- walk ------------------------------------------------------------------------------------------
+    for (uint32_t s = 0; s < n; s++) {
+      if (STATS) st[0]++;
+      const uint32_t dq = (uint32_t)__builtin_amdgcn_readlane((int)dnq, (int)s);
+      // hidden in the whole quadrant: every lane's nearest depth is >= dq (its block lies inside the quadrant)
+      if (!__any(dq <= lane_far)) {
+        if (STATS) st[15]++;
+        continue;
+      }
+      if (STATS) st[1]++;
+      auto bc = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)s); };
+      auto bf = [&](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, (int)s)); };
+      const uint32_t bb0 = bc(c3.w), bb1 = bc(c4.x), flags = bc(c4.y), ridx = bc(myrec);
+      const int x0 = (int)(bb0 & 0xFFFFu), y0 = (int)(bb0 >> 16), x1 = (int)(bb1 & 0xFFFFu), y1 = (int)(bb1 >> 16);
+      raster_entry<STATS, DBG>(lv, prec, bf(c0.x), bf(c0.y), bf(c0.z), bf(c0.w), bf(c1.x), bf(c1.y), bf(c1.z), bf(c1.w), bf(c2.x),
+                               bf(c2.y), bf(c2.z), bf(c2.w), bf(c3.x), bf(c3.y), bf(c3.z), x0, y0, x1, y1, flags, ridx, bx, by,
+                               pxlo, pxhi, pylo, pyhi, best_d, best_r, lane_far,
+                               [&]() -> ShadeRec { return prec[ridx].s; }, st);
+    }
+  }
+  if (STATS && lane == 0)
+    for (int k = 0; k < 16; k++) atomicAdd(&stats[k], st[k]);
+#pragma unroll
+  for (int ry = 0; ry < 4; ry++) {
+    const int iy = by + ry;
+    if (iy < height && bx < width) {
+      const size_t o = ((size_t)pose * (size_t)height + (size_t)iy) * (size_t)width + (size_t)bx;
+      if (vis16)  // record indices fit 16 bits (0xFFFF = none): half the visibility traffic
+        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) =
+            make_uint2((best_r[ry * 4] & 0xFFFFu) | (best_r[ry * 4 + 1] << 16),
+                       (best_r[ry * 4 + 2] & 0xFFFFu) | (best_r[ry * 4 + 3] << 16));
+      else
+        *reinterpret_cast<uint4 *>(vis + o) =
+            make_uint4(best_r[ry * 4], best_r[ry * 4 + 1], best_r[ry * 4 + 2], best_r[ry * 4 + 3]);
+      if (prim_out) {
+        uint32_t p[4];
+#pragma unroll
+        for (int rx = 0; rx < 4; rx++)
+          p[rx] = best_r[ry * 4 + rx] == NONE ? NONE : (prec[best_r[ry * 4 + rx]].r.flags & 0xFFFFFFu);
+        *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p[0], p[1], p[2], p[3]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
+                           const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
+                           int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
+                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out) {
+  const uint32_t n = n_poses;
+  const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)(tiles_x * tiles_y);
+  if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
+  static const bool want_stats = getenv("RDOOM_STATS") != nullptr;
+  if (want_stats) {
+    unsigned long long *d_stats = nullptr, h[16];
+    HIP_TRY(hipMalloc((void **)&d_stats, sizeof h));
+    HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof h, st));
+    hipLaunchKernelGGL(raster_wave_kernel<true>, dim3((uint32_t)nblocks), dim3(256), 0, st, lv, recs, sorted, counts, cap, n,
+                       width, height, tiles_x, tiles_y, tile_hdr, entries, entry_cap, overflow, vis, vis16 ? 1u : 0u,
+                       prim_out, d_stats);
+    HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
+    (void)hipFree(d_stats);
+    const double waves = (double)nblocks * 4.0;
+    fprintf(stderr,
+            "[rdoom stats] per wave: queue %.1f  quadrant-bbox %.1f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
+            "  general %.2f (lanes %.1f: zrange %.1f, rw<=0 %.1f, masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | coarse tests/block %.0f hits %.1f\n",
+            h[0] / waves, h[1] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
+            h[4] ? (double)h[5] / h[4] : 0.0, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
+            h[6] ? (double)h[10] / h[6] : 0.0, h[6] ? (double)h[11] / h[6] : 0.0, h[6] ? (double)h[12] / h[6] : 0.0,
+            h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, (double)h[8] / (double)nblocks,
+            (double)h[9] / (double)nblocks);
+  } else {
+    static const int raster_dbg = getenv("RDOOM_RASTER_DBG") ? atoi(getenv("RDOOM_RASTER_DBG")) : 0;  // timing experiments
+    auto rk = raster_dbg == 1 ? raster_wave_kernel<false, 1>
+                              : (raster_dbg == 2 ? raster_wave_kernel<false, 2> : raster_wave_kernel<false, 0>);
+    hipLaunchKernelGGL(rk, dim3((uint32_t)nblocks), dim3(256), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
+                       tiles_y, tile_hdr, entries, entry_cap, overflow, vis, vis16 ? 1u : 0u, prim_out,
+                       (unsigned long long *)nullptr);
+  }
+  return RDOOM_OK;
+}
+
+}  // namespace rdoom_dev

@@ -1,0 +1,486 @@
+// C ABI of the device renderer (include/rdoom.h "device renderer"): level upload, batch scratch, and
+// rdoom_batch_render = setup -> bin -> raster -> fragment -> fixup on the caller's stream.
+//
+// Replaces the reference's GL draw path: VertexBuffer / IndexBuffer / Texture2d uploads (engine/src/meshes.rs:126-201,
+// engine/src/uniforms.rs:146-221) and the frame.draw loop of Renderer::update (engine/src/renderer.rs:98-157).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace rdoom_dev;
+
+namespace {
+bool is_pow2(uint32_t x) { return x != 0 && (x & (x - 1)) == 0; }
+}  // namespace
+
+struct rdoom_level {
+  int device = 0;
+  DeviceLevelView view{};
+  void *d_tris = nullptr, *d_flat = nullptr, *d_wall = nullptr, *d_sky = nullptr, *d_cmap = nullptr;
+  uint32_t ntri = 0, n_objects = 1;
+};
+
+struct rdoom_batch {
+  const rdoom_level *level = nullptr;
+  uint32_t width = 0, height = 0, max_poses = 0, cap = 0, last_n = 0;
+  PoseConst *d_poses = nullptr;
+  TriRec *d_recs = nullptr;   // max_poses x cap records in near-to-far order (setup -> bin, raster, fragment)
+  TriRec *d_tmp_recs = nullptr;  // same size: setup's compaction-order staging
+  uint4 *d_sorted = nullptr;  // per pose: (bbox, record index, depth bucket) near-to-far (coarse test input)
+  uint2 *d_tile_hdr = nullptr;     // per (pose, tile): (first entry, entry count)
+  uint32_t *d_entries = nullptr;   // per pose: entry_cap tile-list entries (record index | quadrant mask << 28)
+  uint32_t *d_overflow = nullptr;  // per pose: 1 = bins incomplete, rasteriser scans the sorted list
+  uint32_t entry_cap = 0, n_tiles = 0;
+  uint32_t *d_fix_count = nullptr;  // [0] = queued pixels, [1] = error flag (fixup list overflow)
+  uint2 *d_fix_list = nullptr;
+  uint32_t fix_cap = 1u << 20;
+  uint32_t *d_counts = nullptr, *d_vis = nullptr, *d_prim = nullptr;
+  uint8_t *d_fb = nullptr;
+  PoseConst *h_poses = nullptr;  // pinned staging for the per-pose constants
+  ObjectConst *d_objects = nullptr, *h_objects = nullptr;  // max_poses x n_objects, allocated on first use
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_copy = nullptr;  // H2D of h_poses finished: staging may be rewritten
+  bool want_prim = false;
+  bool vis16 = false;  // record indices fit 16 bits: visibility words are u16
+  float *d_ndc = nullptr;  // (ix + 0.5) / (width / 2) - 1 for every column, then (iy + 0.5) / (height / 2) - 1 for every row
+};
+
+extern "C" {
+
+rdoom_status rdoom_device_count(int32_t *out_count) {
+  if (!out_count) return rdoom::fail(RDOOM_BAD_ARG, "out_count is null");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  *out_count = n;
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_set_device(int32_t device) {
+  HIP_TRY(hipSetDevice(device));
+  return RDOOM_OK;
+}
+
+void rdoom_level_destroy(rdoom_level *level) {
+  if (!level) return;
+  for (void *p : {level->d_tris, level->d_flat, level->d_wall, level->d_sky, level->d_cmap})
+    if (p) (void)hipFree(p);
+  delete level;
+}
+
+rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_level) {
+  if (!d || !out_level) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out_level = nullptr;
+  if (!d->colormap) return rdoom::fail(RDOOM_BAD_ARG, "colormap is null");
+  if ((d->flat_w | d->flat_h) && !(is_pow2(d->flat_w) && is_pow2(d->flat_h)))
+    return rdoom::fail(RDOOM_BAD_ARG, "flat atlas %ux%u is not a power of two", d->flat_w, d->flat_h);
+  if ((d->wall_w | d->wall_h) && !(is_pow2(d->wall_w) && is_pow2(d->wall_h)))
+    return rdoom::fail(RDOOM_BAD_ARG, "wall atlas %ux%u is not a power of two", d->wall_w, d->wall_h);
+  if ((d->decor_w | d->decor_h) && !(is_pow2(d->decor_w) && is_pow2(d->decor_h)))
+    return rdoom::fail(RDOOM_BAD_ARG, "decor atlas %ux%u is not a power of two", d->decor_w, d->decor_h);
+  if (d->flat_w > 32768 || d->flat_h > 32768 || d->wall_w > 32768 || d->wall_h > 32768 || d->decor_w > 32768 ||
+      d->decor_h > 32768)
+    return rdoom::fail(RDOOM_BAD_ARG, "atlas larger than 32768 texels on a side");
+  // flatten the draws into one primitive list in draw order (primitive id == position)
+  std::vector<LevelTri> tris;
+  uint32_t n_objects = 1;
+  // Alpha-test classification of a wall texture (all its animation frames): bit 0 = a texel in the
+  // one-texel ring AROUND the rectangle is transparent (the float mod of F2 can land there), bit 1 =
+  // the rectangle itself contains transparent texels (a genuinely masked texture).
+  std::map<std::tuple<float, float, float, float, uint32_t, float>, uint32_t> masked_cache;
+  auto region_masked = [&](const rdoom_static_vertex &v) -> uint32_t {
+    auto key = std::make_tuple(v.a_atlas_uv[0], v.a_atlas_uv[1], v.a_tile_size[0], v.a_tile_size[1],
+                               (uint32_t)v.a_num_frames, v.a_row_height);
+    auto it = masked_cache.find(key);
+    if (it != masked_cache.end()) return it->second;
+    uint32_t m = 0;
+    const double W = d->wall_w, au = v.a_atlas_uv[0], av = v.a_atlas_uv[1], sx = v.a_tile_size[0],
+                 sy = v.a_tile_size[1];
+    const uint32_t nf = v.a_num_frames == 0 ? 1u : v.a_num_frames;
+    for (uint32_t f = 0; f < nf; f++) {
+      double u0 = au + f * sx;
+      double rows = std::ceil((u0 + sx) / W) - 1.0;
+      if (nf == 1) rows = 0;
+      const double md = sx > 0 ? (W - au) - sx * std::floor((W - au) / sx) : 0;
+      u0 += md * rows;
+      const double v0 = av + rows * v.a_row_height;
+      const long xlo = (long)std::floor(u0), xhi = (long)std::ceil(u0 + sx), ylo = (long)std::floor(v0),
+                 yhi = (long)std::ceil(v0 + sy);  // interior = [xlo, xhi) x [ylo, yhi)
+      for (long y = ylo - 1; y <= yhi; y++)
+        for (long x = xlo - 1; x <= xhi; x++) {
+          const uint32_t xx = (uint32_t)x & (d->wall_w - 1), yy = (uint32_t)y & (d->wall_h - 1);
+          if (d->wall_atlas[(size_t)yy * d->wall_w + xx] & 0x8000u)
+            m |= (x >= xlo && x < xhi && y >= ylo && y < yhi) ? 2u : 1u;
+        }
+    }
+    masked_cache[key] = m;
+    return m;
+  };
+  for (uint32_t di = 0; di < d->n_draws; di++) {
+    const rdoom_draw &dr = d->draws[di];
+    if (dr.index_count % 3 != 0) return rdoom::fail(RDOOM_BAD_ARG, "draw %u: index_count not a multiple of 3", di);
+    if (dr.object_id >= 4096u) return rdoom::fail(RDOOM_BAD_LEVEL, "draw %u: object id %u (at most 4095)", di, dr.object_id);
+    n_objects = std::max(n_objects, dr.object_id + 1u);
+    for (uint32_t t = 0; t < dr.index_count / 3; t++) {
+      LevelTri lt;
+      std::memset(&lt, 0, sizeof lt);
+      lt.packed = 1u | (dr.kind << 16);
+      if (dr.kind == RDOOM_KIND_FLAT || dr.kind == RDOOM_KIND_WALL) {
+        if ((uint64_t)dr.first_index + dr.index_count > d->n_static_indices)
+          return rdoom::fail(RDOOM_BAD_ARG, "draw %u: static index range out of bounds", di);
+        const rdoom_static_vertex *vv[3];
+        for (int i = 0; i < 3; i++) {
+          const uint32_t idx = d->static_indices[dr.first_index + 3 * t + i];
+          if (idx >= d->n_static_verts) return rdoom::fail(RDOOM_BAD_ARG, "draw %u: vertex index out of bounds", di);
+          vv[i] = &d->static_verts[idx];
+          std::memcpy(&lt.pos[3 * i], vv[i]->a_pos, 12);
+          lt.uv[2 * i] = vv[i]->a_tile_uv[0];
+          lt.uv[2 * i + 1] = vv[i]->a_tile_uv[1];
+          lt.scroll[i] = vv[i]->a_scroll_rate;
+        }
+        const rdoom_static_vertex &pv = *vv[2];  // flat varyings: provoking (last) vertex
+        lt.atlas_u = pv.a_atlas_uv[0];
+        lt.atlas_v = pv.a_atlas_uv[1];
+        lt.size_x = pv.a_tile_size[0];
+        lt.size_y = pv.a_tile_size[1];
+        lt.row_height = pv.a_row_height;
+        uint32_t masked = 0;
+        if (dr.kind == RDOOM_KIND_WALL) {
+          if (!d->wall_atlas) return rdoom::fail(RDOOM_BAD_ARG, "wall draw without a wall atlas");
+          masked = region_masked(pv);
+        } else if (!d->flat_atlas) {
+          return rdoom::fail(RDOOM_BAD_ARG, "flat draw without a flat atlas");
+        }
+        lt.packed = (uint32_t)pv.a_num_frames | ((uint32_t)pv.a_light << 8) | (dr.kind << 16) |
+                    (masked << 18);
+      } else if (dr.kind == RDOOM_KIND_SKY) {
+        if ((uint64_t)dr.first_index + dr.index_count > d->n_sky_indices)
+          return rdoom::fail(RDOOM_BAD_ARG, "draw %u: sky index range out of bounds", di);
+        for (int i = 0; i < 3; i++) {
+          const uint32_t idx = d->sky_indices[dr.first_index + 3 * t + i];
+          if (idx >= d->n_sky_verts) return rdoom::fail(RDOOM_BAD_ARG, "draw %u: sky vertex out of bounds", di);
+          std::memcpy(&lt.pos[3 * i], &d->sky_verts[3 * idx], 12);
+        }
+      } else if (dr.kind == RDOOM_KIND_DECOR) {
+        if ((uint64_t)dr.first_index + dr.index_count > d->n_decor_indices)
+          return rdoom::fail(RDOOM_BAD_ARG, "draw %u: decor index range out of bounds", di);
+        if (!d->decor_atlas) return rdoom::fail(RDOOM_BAD_ARG, "decor draw without a decor atlas");
+        const rdoom_sprite_vertex *vv[3];
+        for (int i = 0; i < 3; i++) {
+          const uint32_t idx = d->decor_indices[dr.first_index + 3 * t + i];
+          if (idx >= d->n_decor_verts) return rdoom::fail(RDOOM_BAD_ARG, "draw %u: decor vertex out of bounds", di);
+          vv[i] = &d->decor_verts[idx];
+          std::memcpy(&lt.pos[3 * i], vv[i]->a_pos, 12);
+          lt.uv[2 * i] = vv[i]->a_tile_uv[0];
+          lt.uv[2 * i + 1] = vv[i]->a_tile_uv[1];
+          lt.scroll[i] = vv[i]->a_local_x;  // decor triangles carry a_local_x here (sprite.vert:41-42)
+        }
+        const rdoom_sprite_vertex &pv = *vv[2];
+        lt.atlas_u = pv.a_atlas_uv[0];
+        lt.atlas_v = pv.a_atlas_uv[1];
+        lt.size_x = pv.a_tile_size[0];
+        lt.size_y = pv.a_tile_size[1];
+        lt.row_height = pv.a_tile_size[1];  // sprite.vert:37 advances animation rows by the tile height
+        // sprites are alpha tested per pixel (sprite.frag:20): always the exact path of the rasteriser
+        lt.packed = (uint32_t)pv.a_num_frames | ((uint32_t)pv.a_light << 8) | (dr.kind << 16) | (3u << 18);
+      } else {
+        return rdoom::fail(RDOOM_BAD_ARG, "draw %u: unknown kind %u", di, dr.kind);
+      }
+      lt.packed |= dr.object_id << 20;
+      tris.push_back(lt);
+    }
+  }
+  if (tris.size() >= (1u << 24)) return rdoom::fail(RDOOM_BAD_LEVEL, "too many triangles (%zu)", tris.size());
+  rdoom_level *lv = new rdoom_level;
+  (void)hipGetDevice(&lv->device);
+  lv->ntri = (uint32_t)tris.size();
+  lv->n_objects = n_objects;
+  auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+    if (bytes == 0 || !src) {
+      *dst = nullptr;
+      return hipSuccess;
+    }
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  hipError_t e = upload(&lv->d_tris, tris.data(), tris.size() * sizeof(LevelTri));
+  // unified u16 texel store: wall atlas, then (at a multiple of 1024 elements) the flat atlas promoted to u16
+  const size_t wall_n = d->wall_atlas ? (size_t)d->wall_w * d->wall_h : 0;
+  const size_t flat_n = d->flat_atlas ? (size_t)d->flat_w * d->flat_h : 0;
+  const size_t decor_n = d->decor_atlas ? (size_t)d->decor_w * d->decor_h : 0;
+  const size_t flat_base = (wall_n + 1023) / 1024 * 1024;
+  const size_t decor_base = (flat_base + flat_n + 1023) / 1024 * 1024;
+  if (decor_base + decor_n >= ((size_t)1 << 26)) {
+    rdoom_level_destroy(lv);
+    return rdoom::fail(RDOOM_BAD_LEVEL, "atlases too large (%zu texels)", decor_base + decor_n);
+  }
+  std::vector<uint16_t> texels(decor_base + decor_n + 1, 0);  // never empty: masked-off lanes read element 0
+  if (wall_n) std::memcpy(texels.data(), d->wall_atlas, wall_n * 2);
+  for (size_t i = 0; i < flat_n; i++) texels[flat_base + i] = d->flat_atlas[i];
+  if (decor_n) std::memcpy(texels.data() + decor_base, d->decor_atlas, decor_n * 2);
+  if (e == hipSuccess) e = upload(&lv->d_wall, texels.data(), texels.size() * 2);
+  if (e == hipSuccess) e = upload(&lv->d_sky, d->sky_texture, (size_t)d->sky_w * d->sky_h * 2);
+  if (e == hipSuccess) e = upload(&lv->d_cmap, d->colormap, 32 * 256);
+  if (e != hipSuccess) {
+    rdoom_level_destroy(lv);
+    return rdoom::fail(e == hipErrorOutOfMemory ? RDOOM_OOM : RDOOM_HIP_ERROR, "level upload failed: %s",
+                       hipGetErrorString(e));
+  }
+  lv->view.tris = (const LevelTri *)lv->d_tris;
+  lv->view.ntri = lv->ntri;
+  lv->view.texels = (const uint16_t *)lv->d_wall;
+  lv->view.flat_base = (uint32_t)flat_base;
+  lv->view.decor_base = (uint32_t)decor_base;
+  lv->view.decor_w = d->decor_atlas ? d->decor_w : 0;
+  lv->view.decor_h = d->decor_atlas ? d->decor_h : 0;
+  lv->view.flat_w = d->flat_w;
+  lv->view.flat_h = d->flat_h;
+  lv->view.wall_w = d->wall_w;
+  lv->view.wall_h = d->wall_h;
+  lv->view.sky_tex = (const uint16_t *)lv->d_sky;
+  lv->view.sky_w = lv->d_sky ? d->sky_w : 0;
+  lv->view.sky_h = lv->d_sky ? d->sky_h : 0;
+  lv->view.sky_band = d->sky_tiled_band_size;
+  lv->view.colormap = (const uint8_t *)lv->d_cmap;
+  *out_level = lv;
+  return RDOOM_OK;
+}
+
+void rdoom_batch_destroy(rdoom_batch *b) {
+  if (!b) return;
+  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_tmp_recs, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries,
+                  (void *)b->d_overflow, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
+                  (void *)b->d_prim, (void *)b->d_fb})
+    if (p) (void)hipFree(p);
+  for (auto &e : b->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (b->ev_copy) (void)hipEventDestroy(b->ev_copy);
+  if (b->h_poses) (void)hipHostFree(b->h_poses);
+  if (b->h_objects) (void)hipHostFree(b->h_objects);
+  if (b->d_ndc) (void)hipFree(b->d_ndc);
+  if (b->d_objects) (void)hipFree(b->d_objects);
+  delete b;
+}
+
+rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32_t height, uint32_t max_poses,
+                                rdoom_batch **out_batch) {
+  if (!level || !out_batch) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out_batch = nullptr;
+  if (width == 0 || height == 0 || max_poses == 0 || width % 4 != 0 || width > 16384 || height > 16384)
+    return rdoom::fail(RDOOM_BAD_ARG, "bad frame size %ux%u (width must be a multiple of 4) or max_poses %u", width,
+                       height, max_poses);
+  rdoom_batch *b = new rdoom_batch;
+  b->level = level;
+  b->width = width;
+  b->height = height;
+  b->max_poses = max_poses;
+  b->cap = level->ntri ? level->ntri : 1;
+  b->vis16 = b->cap < 0xFFFFu && getenv("RDOOM_VIS32") == nullptr;  // RDOOM_VIS32: tests force the 32-bit words
+  const size_t npx = (size_t)width * height * max_poses;
+  hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_tmp_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_sorted, sizeof(uint4) * (size_t)b->cap * max_poses);
+  b->n_tiles = ((width + TILE_W - 1) / TILE_W) * ((height + TILE_H - 1) / TILE_H);
+  b->entry_cap = std::max<uint32_t>(65536u, 32u * b->n_tiles);  // tile-list entries per pose; beyond it the pose is scanned
+  if (const char *dbg = getenv("RDOOM_ENTRY_CAP")) b->entry_cap = (uint32_t)std::max(1, atoi(dbg));  // tests: force that fallback
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_tile_hdr, sizeof(uint2) * (size_t)b->n_tiles * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_entries, sizeof(uint32_t) * (size_t)b->entry_cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_overflow, sizeof(uint32_t) * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_count, 2 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_list, sizeof(uint2) * (size_t)b->fix_cap);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, sizeof(uint32_t) * npx);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
+  if (e == hipSuccess) {  // sky.frag:13's ndc per column / row, same two operations as the per-pixel form
+    std::vector<float> ndc(width + height);
+    for (uint32_t i = 0; i < width; i++) ndc[i] = ((float)i + 0.5f) / (0.5f * (float)width) - 1.0f;
+    for (uint32_t i = 0; i < height; i++) ndc[width + i] = ((float)i + 0.5f) / (0.5f * (float)height) - 1.0f;
+    e = hipMalloc((void **)&b->d_ndc, sizeof(float) * ndc.size());
+    if (e == hipSuccess) e = hipMemcpy(b->d_ndc, ndc.data(), sizeof(float) * ndc.size(), hipMemcpyHostToDevice);
+  }
+  for (auto &ev : b->ev)
+    if (e == hipSuccess) e = hipEventCreate(&ev);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev_copy);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_poses, sizeof(PoseConst) * max_poses, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    rdoom_batch_destroy(b);
+    return rdoom::fail(e == hipErrorOutOfMemory ? RDOOM_OOM : RDOOM_HIP_ERROR, "batch allocation failed: %s",
+                       hipGetErrorString(e));
+  }
+  *out_batch = b;
+  return RDOOM_OK;
+}
+
+static void mat_mul_v1(const float *P, const float *M, float *pm) {  // V1: PM = P * M, plain multiply/add, left to right
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++)
+      pm[c * 4 + r] = ((P[0 * 4 + r] * M[c * 4 + 0] + P[1 * 4 + r] * M[c * 4 + 1]) + P[2 * 4 + r] * M[c * 4 + 2]) +
+                      P[3 * 4 + r] * M[c * 4 + 3];
+}
+
+static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const uint8_t *lights, uint32_t lights_stride,
+                                uint32_t n, uint32_t kinds_mask, hipStream_t st, rdoom_timings *tm,
+                                const float *object_modelviews = nullptr, uint32_t n_objects = 0) {
+  if (!b || !poses || !lights) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  if (n == 0 || n > b->max_poses) return rdoom::fail(RDOOM_BAD_ARG, "n_poses %u outside 1..%u", n, b->max_poses);
+  const rdoom_level *lv = b->level;
+  if (object_modelviews && n_objects < lv->n_objects)
+    return rdoom::fail(RDOOM_BAD_ARG, "n_objects %u but the level draws objects 0..%u", n_objects, lv->n_objects - 1);
+  HIP_TRY(hipEventSynchronize(b->ev_copy));  // previous render's H2D must be done before restaging
+  if (object_modelviews) {
+    const size_t count = (size_t)b->max_poses * lv->n_objects;
+    if (!b->d_objects) HIP_TRY(hipMalloc((void **)&b->d_objects, sizeof(ObjectConst) * count));
+    if (!b->h_objects) HIP_TRY(hipHostMalloc((void **)&b->h_objects, sizeof(ObjectConst) * count, hipHostMallocDefault));
+    for (uint32_t p = 0; p < n; p++)
+      for (uint32_t o = 0; o < lv->n_objects; o++) {
+        ObjectConst &oc = b->h_objects[(size_t)p * lv->n_objects + o];
+        const float *M = object_modelviews + ((size_t)p * n_objects + o) * 16;
+        mat_mul_v1(poses[p].projection, M, oc.pm);
+        std::memcpy(oc.mv, M, sizeof oc.mv);
+        oc.vr0 = atan2f(oc.pm[8], oc.pm[10]);  // sky.vert:10-12
+        oc.vr1 = oc.pm[9] / oc.pm[11];
+        oc.pad0 = oc.pad1 = 0;
+      }
+  }
+  for (uint32_t p = 0; p < n; p++) {  // V1: PM = P * M, plain multiply/add, left to right
+    PoseConst &pc = b->h_poses[p];
+    const float *P = poses[p].projection, *M = poses[p].modelview;
+    mat_mul_v1(P, M, pc.pm);
+    std::memcpy(pc.mv, M, sizeof pc.mv);
+    std::memcpy(pc.proj, P, sizeof pc.proj);
+    pc.time = poses[p].time;
+    pc.vr0 = atan2f(pc.pm[8], pc.pm[10]);  // sky.vert:10-12
+    pc.vr1 = pc.pm[9] / pc.pm[11];
+    pc.pad = 0;
+    std::memcpy(pc.lights, lights + (size_t)p * lights_stride, 256);
+  }
+  b->last_n = n;
+  if (tm) HIP_TRY(hipEventRecord(b->ev[0], st));
+  HIP_TRY(hipMemcpyAsync(b->d_poses, b->h_poses, sizeof(PoseConst) * n, hipMemcpyHostToDevice, st));
+  if (object_modelviews)
+    HIP_TRY(hipMemcpyAsync(b->d_objects, b->h_objects, sizeof(ObjectConst) * (size_t)n * lv->n_objects,
+                           hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(b->ev_copy, st));
+  const int W = (int)b->width, H = (int)b->height;
+  if (lv->ntri)
+    launch_setup(st, n, lv->view, b->d_poses, object_modelviews ? (const ObjectConst *)b->d_objects : nullptr, lv->n_objects,
+                 W, H, kinds_mask, b->d_recs, b->d_tmp_recs, b->d_sorted, b->d_counts, b->cap);
+  const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+  static const bool no_bins = getenv("RDOOM_NO_BINS") != nullptr;  // debug: exercise the fallback scan
+  if (lv->ntri && !no_bins) {
+    launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap,
+               b->d_overflow);
+  } else {
+    HIP_TRY(hipMemsetAsync(b->d_overflow, 0xFF, sizeof(uint32_t) * n, st));
+    if (!lv->ntri) HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
+  }
+  if (tm) HIP_TRY(hipEventRecord(b->ev[1], st));
+  uint32_t *prim_out = b->want_prim ? b->d_prim : nullptr;
+  if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, W, H, tiles_x, tiles_y,
+                                      b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out))
+    return rs;
+  if (tm) HIP_TRY(hipEventRecord(b->ev[2], st));
+  if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, b->d_poses, W, H, tiles_x,
+                                        tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16,
+                                        prim_out, b->d_ndc, b->d_fb, b->d_fix_count, b->d_fix_list, b->fix_cap))
+    return rs;
+  HIP_TRY(hipGetLastError());
+  if (tm) {
+    HIP_TRY(hipEventRecord(b->ev[3], st));
+    HIP_TRY(hipEventSynchronize(b->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&tm->setup_ms, b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&tm->raster_ms, b->ev[1], b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&tm->fragment_ms, b->ev[2], b->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&tm->total_ms, b->ev[0], b->ev[3]));
+    tm->pixels = (uint64_t)n * W * H;
+    std::vector<uint32_t> counts(n);
+    HIP_TRY(hipMemcpy(counts.data(), b->d_counts, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    tm->visible_triangles = 0;
+    for (uint32_t c : counts) tm->visible_triangles += c;
+    uint32_t fix[2] = {0, 0};
+    HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
+    tm->fixup_pixels = fix[0];
+    if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
+  }
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_batch_render(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream) {
+  return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, nullptr);
+}
+
+rdoom_status rdoom_batch_render_timed(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                      uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
+                                      rdoom_timings *out) {
+  if (!out) return rdoom::fail(RDOOM_BAD_ARG, "out is null");
+  return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, out);
+}
+
+rdoom_status rdoom_batch_render_objects(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                        uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
+                                        const float *object_modelviews, uint32_t n_objects) {
+  if (!object_modelviews) return rdoom::fail(RDOOM_BAD_ARG, "object_modelviews is null");
+  return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, nullptr,
+                     object_modelviews, n_objects);
+}
+
+rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out) {
+  if (!level || !out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out = level->n_objects;
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **out_device_ptr) {
+  if (!batch || !out_device_ptr) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out_device_ptr = batch->d_fb;
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *b, uint32_t first, uint32_t count, uint8_t *host_out) {
+  if (!b || !host_out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  if ((uint64_t)first + count > b->last_n) return rdoom::fail(RDOOM_BAD_ARG, "frame range outside the last render");
+  const size_t frame = (size_t)b->width * b->height;
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t fix[2] = {0, 0};
+  HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
+  if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
+  HIP_TRY(hipMemcpy(host_out, b->d_fb + frame * first, frame * count, hipMemcpyDeviceToHost));
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_batch_enable_primitive_ids(rdoom_batch *b) {
+  if (!b) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  if (!b->d_prim) {
+    const size_t npx = (size_t)b->width * b->height * b->max_poses;
+    HIP_TRY(hipMalloc((void **)&b->d_prim, sizeof(uint32_t) * npx));
+  }
+  b->want_prim = true;
+  b->last_n = 0;  // nothing captured yet: render first
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_batch_read_primitive_ids(rdoom_batch *b, uint32_t first, uint32_t count, uint32_t *host_out) {
+  if (!b || !host_out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  if (!b->want_prim || !b->d_prim)
+    return rdoom::fail(RDOOM_BAD_ARG, "primitive ids are not captured: call rdoom_batch_enable_primitive_ids, then render");
+  if ((uint64_t)first + count > b->last_n) return rdoom::fail(RDOOM_BAD_ARG, "frame range outside the last render");
+  const size_t frame = (size_t)b->width * b->height;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_out, b->d_prim + frame * first, frame * count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return RDOOM_OK;
+}
+
+}  // extern "C"

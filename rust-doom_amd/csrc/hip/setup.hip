@@ -1,0 +1,286 @@
+// Kernel 1: vertex stage + triangle setup + near-to-far ordering.
+//
+// Part of the pose-batch renderer for gfx950 (MI355X) that replaces the reference's GL draw path:
+// assets/shaders/static.{vert,frag}, sky.{vert,frag}, sprite.{vert,frag} and the fixed-function state of
+// engine/src/renderer.rs:49-57 + engine/src/window.rs:12,40-44.  The arithmetic is specified in DESIGN.md
+// "Raster arithmetic"; operation order follows that text, not the oracle's source.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rdoom_dev {
+namespace {
+
+// =================================================================================================
+// Kernel 1: vertex stage + triangle setup (V2..V5, S1..S6) and front-to-back ordering.
+// One 256-thread workgroup per pose walks the level's triangle list in chunks; visible triangles are
+// compacted in order (ballot + prefix) into the pose's record array, then a counting sort over a
+// log-depth bucket (exponent + top mantissa bits of the nearest vertex's w) produces the `sorted`
+// list the rasteriser consumes: near geometry first, so its exact early-z test rejects most occluded
+// triangles.  The order only affects speed: the winner is the lexicographic min of (d24, primitive).
+// =================================================================================================
+constexpr uint32_t SORT_BUCKETS = 2048;
+constexpr uint32_t SORT_KEY_CAP = 8192;  // visible triangles per pose whose keys fit the LDS key array (more: unsorted, still correct)
+
+__device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const PoseConst &pc,
+                                               const ObjectConst *__restrict__ objs, uint32_t t, int width,
+                                               int height, uint32_t kinds_mask, RasterRec &rr, ShadeRec &sr,
+                                               float &wkey) {
+  wkey = 0.0f;
+  bool ok = t < lv.ntri;
+  if (ok) {
+    const LevelTri tri = lv.tris[t];
+    const uint32_t kind = (tri.packed >> 16) & 3u;
+    ok = ((kinds_mask >> kind) & 1u) != 0u;
+    if (ok) {
+      // uniforms of this triangle's object: the pose's own unless objects move
+      const float *pm = pc.pm, *mv = pc.mv;
+      float vr0 = pc.vr0, vr1 = pc.vr1;
+      if (objs) {
+        const ObjectConst &oc = objs[tri.packed >> 20];
+        pm = oc.pm, mv = oc.mv, vr0 = oc.vr0, vr1 = oc.vr1;
+      }
+      float clip[3][4], u[3], v[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const float x = tri.pos[3 * i], y = tri.pos[3 * i + 1], z = tri.pos[3 * i + 2];
+        if (kind == RDOOM_KIND_DECOR) {
+          // D1..D3 (sprite.vert:41-46): camera-facing expansion along row 0 of the modelview, then
+          // projection * (modelview * pos) in two steps
+          const float lx = tri.scroll[i];
+          const float px = fmaf(mv[0], lx, x), py = fmaf(mv[4], lx, y), pz = fmaf(mv[8], lx, z);
+          float eye[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) eye[r] = fmaf(mv[8 + r], pz, fmaf(mv[4 + r], py, fmaf(mv[r], px, mv[12 + r])));
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            clip[i][r] = fmaf(pc.proj[12 + r], eye[3], fmaf(pc.proj[8 + r], eye[2], fmaf(pc.proj[4 + r], eye[1], pc.proj[r] * eye[0])));
+          u[i] = tri.uv[2 * i];  // sprite.vert:24: no scroll
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            clip[i][r] = fmaf(pm[8 + r], z, fmaf(pm[4 + r], y, fmaf(pm[r], x, pm[12 + r])));
+          u[i] = tri.uv[2 * i] + pc.time * tri.scroll[i];
+        }
+        v[i] = tri.uv[2 * i + 1];
+      }
+      // flat varyings (provoking vertex data were folded into LevelTri on the host)
+      const uint32_t nframes = tri.packed & 0xFFu;
+      float au = tri.atlas_u, av = tri.atlas_v;
+      if (kind == RDOOM_KIND_SKY) au = vr0, av = vr1;  // sky records carry v_r (flat varying of sky.vert) here
+      if (nframes != 1u && kind != RDOOM_KIND_SKY) {
+        const float aw = kind == RDOOM_KIND_FLAT ? (float)lv.flat_w : (kind == RDOOM_KIND_DECOR ? (float)lv.decor_w : (float)lv.wall_w);
+        const float anim_fps = 8.0f / 35.0f;
+        float fi = pc.time / anim_fps;
+        fi = floorf(glsl_mod(fi, (float)nframes));
+        float atlas_u = tri.atlas_u + fi * tri.size_x;
+        const float rows_down = ceilf((atlas_u + tri.size_x) / aw) - 1.0f;
+        atlas_u = atlas_u + glsl_mod(aw - tri.atlas_u, tri.size_x) * rows_down;
+        au = atlas_u;
+        av = tri.atlas_v + rows_down * tri.row_height;
+      }
+      ok = !(clip[0][3] <= 0.0f && clip[1][3] <= 0.0f && clip[2][3] <= 0.0f);
+      if (ok) {
+        const float hw = 0.5f * (float)width, hh = 0.5f * (float)height;
+        float xw[3], yw[3], w[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          xw[i] = (clip[i][0] + clip[i][3]) * hw;
+          yw[i] = (clip[i][1] + clip[i][3]) * hh;
+          w[i] = clip[i][3];
+        }
+        uint32_t tl = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const int j = (i + 1) % 3, k = (i + 2) % 3;
+          const float A = dop(yw[j], w[k], yw[k], w[j]);
+          const float B = dop(xw[k], w[j], xw[j], w[k]);
+          const float C = dop(xw[j], yw[k], xw[k], yw[j]);
+          rr.e[3 * i] = A;
+          rr.e[3 * i + 1] = B;
+          rr.e[3 * i + 2] = C;
+          if ((A > 0.0f) || (A == 0.0f && B > 0.0f)) tl |= 1u << i;
+        }
+        const float det = fmaf(w[0], rr.e[2], fmaf(yw[0], rr.e[1], xw[0] * rr.e[0]));
+        ok = det > 0.0f;
+        if (ok) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const float e0 = rr.e[c], e1 = rr.e[3 + c], e2 = rr.e[6 + c];
+            const float nz = fmaf(clip[2][2], e2, fmaf(clip[1][2], e1, clip[0][2] * e0));
+            const float n1 = (e0 + e1) + e2;
+            const float nu = fmaf(u[2], e2, fmaf(u[1], e1, u[0] * e0));
+            const float nv = fmaf(v[2], e2, fmaf(v[1], e1, v[0] * e0));
+            rr.zp[c] = 0.5f * (nz / det);
+            rr.wp[c] = n1 / det;
+            sr.up[c] = nu / det;
+            sr.vp[c] = nv / det;
+          }
+          rr.zp[2] = rr.zp[2] + 0.5f;
+          int x0 = 0, y0 = 0, x1 = width - 1, y1 = height - 1;
+          const float wmin = fminf(w[0], fminf(w[1], w[2]));
+          wkey = wmin;
+          if (wmin >= 1e-5f) {
+            float sx[3], sy[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+              sx[i] = xw[i] / w[i];
+              sy[i] = yw[i] / w[i];
+            }
+            const float fx0 = floorf(fminf(sx[0], fminf(sx[1], sx[2]))) - 1.0f;
+            const float fx1 = ceilf(fmaxf(sx[0], fmaxf(sx[1], sx[2]))) + 1.0f;
+            const float fy0 = floorf(fminf(sy[0], fminf(sy[1], sy[2]))) - 1.0f;
+            const float fy1 = ceilf(fmaxf(sy[0], fmaxf(sy[1], sy[2]))) + 1.0f;
+            ok = fx0 <= (float)(width - 1) && fx1 >= 0.0f && fy0 <= (float)(height - 1) && fy1 >= 0.0f;
+            if (ok) {
+              x0 = (int)fmaxf(fx0, 0.0f);
+              y0 = (int)fmaxf(fy0, 0.0f);
+              x1 = (int)fminf(fx1, (float)(width - 1));
+              y1 = (int)fminf(fy1, (float)(height - 1));
+            }
+          }
+          rr.bb0 = (uint32_t)x0 | ((uint32_t)y0 << 16);
+          rr.bb1 = (uint32_t)x1 | ((uint32_t)y1 << 16);
+          const uint32_t masked = (tri.packed >> 18) & 3u;  // border, interior
+          rr.flags = (t & 0xFFFFFFu) | (tl << 24) | (kind << 27) | (masked << 29);
+          rr.pad[0] = rr.pad[1] = 0;
+          sr.wp[0] = rr.wp[0];
+          sr.wp[1] = rr.wp[1];
+          sr.wp[2] = rr.wp[2];
+          sr.atlas_u = au;
+          sr.atlas_v = av;
+          sr.size_x = kind == RDOOM_KIND_SKY ? 4.0f * au / 3.14159265358f : tri.size_x;  // sky: the u shift of sky.frag:15
+          sr.size_y = tri.size_y;
+          sr.light = (float)pc.lights[(tri.packed >> 8) & 0xFFu] / 255.0f;
+          const uint32_t bx = __float_as_uint(tri.size_x), by = __float_as_uint(tri.size_y);
+          const bool p2x = (bx & 0x7FFFFFu) == 0u && tri.size_x > 0.0f, p2y = (by & 0x7FFFFFu) == 0u && tri.size_y > 0.0f;
+          const bool is_flat = kind == RDOOM_KIND_FLAT, is_decor = kind == RDOOM_KIND_DECOR;
+          const uint32_t aw = is_flat ? lv.flat_w : (is_decor ? lv.decor_w : lv.wall_w);
+          const uint32_t ah = is_flat ? lv.flat_h : (is_decor ? lv.decor_h : lv.wall_h);
+          const uint32_t tbase = is_flat ? lv.flat_base : (is_decor ? lv.decor_base : 0u);
+          const uint32_t lw = aw ? 31u - (uint32_t)__clz(aw) : 0u;
+          auto packed_ok = [](float sz, bool p2) {
+            return p2 ? (sz >= 0x1p-20f && sz <= 0x1p20f) : (sz >= 1.0f && sz <= 4096.0f && floorf(sz) == sz);
+          };
+          const bool fast_ok = packed_ok(tri.size_x, p2x) && packed_ok(tri.size_y, p2y) && kind <= RDOOM_KIND_WALL;
+          sr.flags = kind | (p2x ? SHADE_POW2_X : 0u) | (p2y ? SHADE_POW2_Y : 0u) | (fast_ok ? SHADE_FAST : 0u) |
+                     ((p2x && p2y) ? 0u : SHADE_NP2) | (lw << 8) | ((tbase >> 10) << 16);
+          sr.tex = kind == RDOOM_KIND_SKY ? 0u : (((aw - 1u) & 0xFFFFu) | (((ah - 1u) & 0xFFFFu) << 16));
+        }
+      }
+    }
+  }
+  return ok;
+}
+
+__device__ __forceinline__ uint32_t depth_bucket(float wmin) {
+  // monotone in wmin: 16 binades [2^-8, 2^8) x 128 steps; anything nearer (or behind the eye) -> 0
+  if (!(wmin > 0.00390625f)) return 0u;
+  const uint32_t b = (__float_as_uint(wmin) >> 16) - (0x3B80u);  // 0x3B800000 = 2^-8
+  return min(b, SORT_BUCKETS - 1u);
+}
+
+__global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
+                                                    const ObjectConst *__restrict__ objects, uint32_t n_objects,
+                                                    int width, int height, uint32_t kinds_mask,
+                                                    TriRec *__restrict__ recs, TriRec *__restrict__ tmp_recs,
+                                                    uint4 *__restrict__ sorted, uint32_t *__restrict__ counts,
+                                                    uint32_t cap) {
+  __shared__ uint32_t hist[SORT_BUCKETS];
+  __shared__ uint16_t keys[SORT_KEY_CAP];
+  __shared__ uint32_t wcnt[4];
+  __shared__ uint32_t scan_tmp[256];
+  const uint32_t pose = blockIdx.x;
+  const PoseConst &pc = poses[pose];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  TriRec *prec = recs + (size_t)pose * cap;
+  TriRec *ptmp = tmp_recs + (size_t)pose * cap;  // records in compaction (= primitive) order, before the sort
+  uint4 *psorted = sorted + (size_t)pose * cap;
+  for (uint32_t i = tid; i < SORT_BUCKETS; i += 256) hist[i] = 0;
+  __syncthreads();
+  uint32_t n = 0;  // visible so far (uniform)
+  for (uint32_t base = 0; base < lv.ntri; base += 256u) {
+    const uint32_t t = base + (uint32_t)tid;
+    RasterRec rr;
+    ShadeRec sr;
+    float wkey;
+    const bool ok = t < lv.ntri && setup_triangle(lv, pc, objects ? objects + (size_t)pose * n_objects : nullptr, t,
+                                                  width, height, kinds_mask, rr, sr, wkey);
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint32_t c = wcnt[w];
+      if (w < wave) off += c;
+      total += c;
+    }
+    if (ok) {
+      ptmp[off].r = rr;
+      ptmp[off].s = sr;
+      const uint32_t bucket = depth_bucket(wkey);
+      if (off < SORT_KEY_CAP) {
+        keys[off] = (uint16_t)bucket;
+        atomicAdd(&hist[bucket], 1u);
+      }
+    }
+    n += total;
+    __syncthreads();
+  }
+  if (tid == 0) counts[pose] = n;
+  const bool sortable = n <= SORT_KEY_CAP;  // else too many for the LDS key array: primitive order (still correct)
+  if (sortable) {
+    // exclusive scan of the histogram: 8 buckets per thread + a 256-wide block scan
+    uint32_t local[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      local[k] = sum;
+      sum += hist[tid * 8 + k];
+    }
+    scan_tmp[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
+      __syncthreads();
+      scan_tmp[tid] += v;
+      __syncthreads();
+    }
+    const uint32_t before = scan_tmp[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < 8; k++) hist[tid * 8 + k] = before + local[k];
+    __syncthreads();
+  }
+  // move every record to its near-to-far position: record index == position in the sorted list from here on
+  // (bin/raster/fragment gather records by that index; ptmp was written by this workgroup, same CU, after a barrier)
+  for (uint32_t i = tid; i < n; i += 256) {
+    const uint32_t bucket = sortable ? (uint32_t)keys[i] : 0u;
+    const uint32_t pos = sortable ? atomicAdd(&hist[bucket], 1u) : i;
+    const uint4 *src = reinterpret_cast<const uint4 *>(&ptmp[i]);
+    uint4 *dst = reinterpret_cast<uint4 *>(&prec[pos]);
+    uint4 v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = src[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) dst[k] = v[k];
+    psorted[pos] = make_uint4(v[3].w, v[4].x, pos, bucket);  // RasterRec::bb0, bb1 (dwords 15, 16)
+  }
+}
+
+}  // namespace
+
+void launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
+                  const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
+                  TriRec *recs, TriRec *tmp_recs, uint4 *sorted, uint32_t *counts, uint32_t cap) {
+  hipLaunchKernelGGL(setup_kernel, dim3(n_poses), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,
+                     kinds_mask, recs, tmp_recs, sorted, counts, cap);
+}
+
+}  // namespace rdoom_dev
