@@ -301,7 +301,7 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_count, 2 * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_list, sizeof(uint2) * (size_t)b->fix_cap);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, sizeof(uint32_t) * npx);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, (b->vis16 ? sizeof(uint16_t) : sizeof(uint32_t)) * npx);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
   if (e == hipSuccess) {  // sky.frag:13's ndc per column / row, same two operations as the per-pixel form
     std::vector<float> ndc(width + height);
