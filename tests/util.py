@@ -30,6 +30,24 @@ def ensure_wad():
     return WAD_PATH
 
 
+BIG_WAD_PATH = os.path.join(GOLDEN, 'synth_big.wad')
+
+
+def ensure_big_wad():
+    """A second synthetic IWAD with ONE level ten times the size of E1M1 (7.2 k linedefs, 3 k sub-sectors, ~36 k
+    triangles: larger than any level of DOOM / DOOM2), generated on demand like the first."""
+    if not os.path.exists(BIG_WAD_PATH):
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import mkwad
+        wad, _ = mkwad.build_wad(1993, specs=[('E1M1', ('gen', 424242, 128, 90))])
+        os.makedirs(GOLDEN, exist_ok=True)
+        tmp = '%s.%d.tmp' % (BIG_WAD_PATH, os.getpid())
+        with open(tmp, 'wb') as f:
+            f.write(wad)
+        os.replace(tmp, BIG_WAD_PATH)
+    return BIG_WAD_PATH
+
+
 def wad_digest():
     with open(ensure_wad(), 'rb') as f:
         return hashlib.sha256(f.read()).hexdigest()

@@ -913,7 +913,8 @@ def level_lumps(L, rng):
     return lumps, stats
 
 
-def build_wad(seed=1993, verbose=False):
+def build_wad(seed=1993, verbose=False, specs=None):
+    """specs (optional): list of (level name, ('gen', seed, grid, rooms) | ('kat',)) replacing the nine default levels."""
     rng = Rng(seed)
     pals = make_playpal()
     cmaps = make_colormap(pals[0])
@@ -931,7 +932,7 @@ def build_wad(seed=1993, verbose=False):
     lumps.append(('TEXTURE1', struct.pack('<I', len(textures)) + b''.join(struct.pack('<I', o) for o in offs) + body))
     lumps.append(('PNAMES', struct.pack('<I', len(pnames)) + b''.join(name8(n) for n in pnames)))
     stats = {}
-    specs = [('E1M1', ('gen', seed * 7 + 1, 52, 14)), ('E1M2', ('kat',)), ('E1M3', ('gen', seed * 7 + 3, 40, 9)),
+    specs = specs or [('E1M1', ('gen', seed * 7 + 1, 52, 14)), ('E1M2', ('kat',)), ('E1M3', ('gen', seed * 7 + 3, 40, 9)),
              ('E1M4', ('gen', seed * 7 + 4, 44, 11)), ('E1M5', ('gen', seed * 7 + 5, 48, 12)),
              ('E1M6', ('gen', seed * 7 + 6, 56, 16)), ('E1M7', ('gen', seed * 7 + 7, 36, 8)),
              ('E1M8', ('gen', seed * 7 + 8, 60, 18)), ('E1M9', ('gen', seed * 7 + 9, 42, 10))]
