@@ -105,9 +105,7 @@ __device__ __forceinline__ void raster_entry(const DeviceLevelView &lv, const Tr
     if (__any(need & (!fast | redo))) {
       if (STATS) {
         st[6]++, st[7] += (unsigned long long)__popcll(__ballot(need & (!fast | redo)));
-        // why: [10] depth range, [11] 1/w <= 0 in the block, [12] masked texture, [13] tie replay
-        st[10] += (unsigned long long)__popcll(__ballot(need & !((zn >= 0.0f) & (zf <= 1.0f))));
-        st[11] += (unsigned long long)__popcll(__ballot(need & !(rwn > 0.0f)));
+        // why: [12] masked texture, [13] tie replay
         st[12] += (unsigned long long)__popcll(__ballot(need & ((flags & RASTER_MASKED_INTERIOR) != 0u)));
         st[13] += (unsigned long long)__popcll(__ballot(need & fast & redo));
       }
@@ -179,7 +177,7 @@ __device__ __forceinline__ void raster_entry(const DeviceLevelView &lv, const Tr
 //                 One compare against the lanes' farthest depths skips a hidden triangle before anything
 //                 else is touched (most rejections are of this kind).
 // =================================================================================================
-template <bool STATS, int DBG = 0>  // DBG: timing experiments only (1 = no queue walk, 2 = reject tests but no pixel bodies)
+template <bool STATS, int DBG = 0>  // DBG: timing experiments only (1 = no queue walk, 2 = reject tests but no pixel bodies, 3 = no quadrant-cover path)
 __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                              const uint4 *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts, uint32_t cap,
@@ -192,6 +190,7 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
                                                              unsigned long long *__restrict__ stats) {
   unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __shared__ uint32_t wq[4][64];
+  __shared__ uint4 wrec[4][64][4];  // per wave: 15 words of each of the 64 gathered raster records
   const uint32_t b = blockIdx.x;
   const uint32_t T = (uint32_t)(tiles_x * tiles_y);
   const uint32_t g = b >> 3;
@@ -199,7 +198,7 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
   const uint32_t tile = g % T;
   if (pose >= n_poses) return;
   const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE_W, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE_H;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave: an SGPR
   const int qx0 = tx0 + (wave & 1) * 32, qy0 = ty0 + (wave >> 1) * 32;  // this wave's quadrant
   const int bx = qx0 + (lane & 7) * 4, by = qy0 + (lane >> 3) * 4;      // this lane's 4x4 block
   const float pxlo = (float)bx + 0.5f, pxhi = (float)bx + 3.5f, pylo = (float)by + 0.5f, pyhi = (float)by + 3.5f;
@@ -235,7 +234,11 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
         const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
         if (x0 <= qx0 + 31 && x1 >= qx0 && y0 <= qy0 + 31 && y1 >= qy0) {
           const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[cand]);
-          rel = rect_may_touch(rp[0], rp[1], rp[2], qxl, qxh, qyl, qyh);
+          // (rare path: the barrier keeps the compiler from hoisting its vectorised corner constants out of the
+          // loop, where they would cost the hot path registers)
+          float lxl = qxl, lxh = qxh, lyl = qyl, lyh = qyh;
+          asm volatile("" : "+v"(lxl), "+v"(lxh), "+v"(lyl), "+v"(lyh));
+          rel = rect_may_touch(rp[0], rp[1], rp[2], lxl, lxh, lyl, lyh);
         }
       }
     }
@@ -252,21 +255,41 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier readers of myq are done
     if (rel) myq[rank] = cand;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // ---- records: lane s holds entry s ---------------------------------------------------------------
+    // ---- records: lane s gathers entry s ------------------------------------------------------------
     const bool have = (uint32_t)lane < n;
     const uint32_t myrec = have ? myq[lane] : 0u;
-    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0, c4 = c0;
+    // nearest depth of my entry's plane over the quadrant (exact corner argument), as d24; none if beyond far;
+    // and whether my entry covers the whole quadrant, so that its pixels need depth compares only (same argument:
+    // the smallest computed value of each edge function, of the depth and of 1/w over the quadrant sits at a corner).
+    // Only the depth plane stays in registers; the rest of the record waits in LDS for the entries that need it.
+    uint32_t dnq = NONE, zpa = 0u, zpb = 0u, zpc = 0u;
+    bool qcov = false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier readers of mine are done
     if (have) {
       const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[myrec]);
-      c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3], c4 = rp[4];
-    }
-    // nearest depth of my entry's plane over the quadrant (exact corner argument), as d24; none if beyond far
-    uint32_t dnq = NONE;
-    {
+      const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3];
+      const uint2 c4 = *reinterpret_cast<const uint2 *>(rp + 4);
+      uint4 *mine = wrec[wave][lane];
+      mine[0] = c0, mine[1] = c1, mine[2] = c3, mine[3] = make_uint4(c2.x, c4.x, c4.y, 0u);
+      zpa = c2.y, zpb = c2.z, zpc = c2.w;
+      const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
+                  e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
+                  e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x);
       const float za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
-      const float zn = fmaf(za, za > 0.0f ? qxl : qxh, fmaf(zb, zb > 0.0f ? qyl : qyh, zc));
-      if (have && zn <= 1.0f) dnq = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
+      const float wa = __uint_as_float(c3.x), wb = __uint_as_float(c3.y), wc = __uint_as_float(c3.z);
+      const float zn = fmaf(za, pos(za) ? qxl : qxh, fmaf(zb, pos(zb) ? qyl : qyh, zc));
+      const float zf = fmaf(za, pos(za) ? qxh : qxl, fmaf(zb, pos(zb) ? qyh : qyl, zc));
+      if (zn <= 1.0f) dnq = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
+      const float n0 = fmaf(e0a, pos(e0a) ? qxl : qxh, fmaf(e0b, pos(e0b) ? qyl : qyh, e0c));
+      const float n1 = fmaf(e1a, pos(e1a) ? qxl : qxh, fmaf(e1b, pos(e1b) ? qyl : qyh, e1c));
+      const float n2 = fmaf(e2a, pos(e2a) ? qxl : qxh, fmaf(e2b, pos(e2b) ? qyl : qyh, e2c));
+      const float rwn = fmaf(wa, pos(wa) ? qxl : qxh, fmaf(wb, pos(wb) ? qyl : qyh, wc));
+      const int x0 = (int)(c3.w & 0xFFFFu), y0 = (int)(c3.w >> 16), x1 = (int)(c4.x & 0xFFFFu), y1 = (int)(c4.x >> 16);
+      qcov = (n0 > 0.0f) & (n1 > 0.0f) & (n2 > 0.0f) & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) & (x0 <= qx0) &
+             (x1 >= qx0 + 31) & (y0 <= qy0) & (y1 >= qy0 + 31) & ((c4.y & RASTER_MASKED_INTERIOR) == 0u);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const unsigned long long qcm = DBG == 3 ? 0ull : __ballot(qcov);
     // ---- walk ------------------------------------------------------------------------------------------
     for (uint32_t s = 0; s < n; s++) {
       if (STATS) st[0]++;
@@ -279,12 +302,50 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
       if (STATS) st[1]++;
       auto bc = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)s); };
       auto bf = [&](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, (int)s)); };
-      const uint32_t bb0 = bc(c3.w), bb1 = bc(c4.x), flags = bc(c4.y), ridx = bc(myrec);
+      const float za = bf(zpa), zb = bf(zpb), zc = bf(zpc);
+      const uint32_t ridx = bc(myrec);
+      if ((qcm >> s) & 1ull) {
+        // the triangle covers the whole quadrant, inside its bbox, the depth range and in front of the eye, texture
+        // rectangle opaque: depth compares only.  (Lanes whose block is hidden lose every compare.)  A depth tie is
+        // replayed through the regular path below, which re-resolves the block exactly.
+        if (STATS) st[10]++;
+        if (DBG == 2) {
+          best_r[0] = ridx;
+          continue;
+        }
+        bool tie = false, updated = false;
+#pragma unroll
+        for (int ry = 0; ry < 4; ry++) {
+          const float tz = fmaf(zb, pylo + (float)ry, zc);
+#pragma unroll
+          for (int rx = 0; rx < 4; rx++) {
+            const int k = ry * 4 + rx;
+            const uint32_t d24 = __float2uint_rz(fmaf(fmaf(za, pxlo + (float)rx, tz), 16777215.0f, 0.5f));
+            const bool win = d24 < best_d[k];
+            tie |= d24 == best_d[k];
+            best_d[k] = win ? d24 : best_d[k];
+            best_r[k] = win ? ridx : best_r[k];
+            updated |= win;
+          }
+        }
+        if (updated) {
+          uint32_t m = best_d[0];
+#pragma unroll
+          for (int k = 1; k < 16; k++) m = max(m, best_d[k]);
+          lane_far = m;
+        }
+        if (!__any(tie)) continue;
+      }
+      // the rest of the record: uniform LDS reads, made SGPR operands
+      const uint4 *wr = wrec[wave][s];
+      const uint4 r0 = wr[0], r1 = wr[1], r2 = wr[2], r3 = wr[3];
+      auto uf = [](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)v)); };
+      auto uu = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+      const uint32_t bb0 = uu(r2.w), bb1 = uu(r3.y), flags = uu(r3.z);
       const int x0 = (int)(bb0 & 0xFFFFu), y0 = (int)(bb0 >> 16), x1 = (int)(bb1 & 0xFFFFu), y1 = (int)(bb1 >> 16);
-      raster_entry<STATS, DBG>(lv, prec, bf(c0.x), bf(c0.y), bf(c0.z), bf(c0.w), bf(c1.x), bf(c1.y), bf(c1.z), bf(c1.w), bf(c2.x),
-                               bf(c2.y), bf(c2.z), bf(c2.w), bf(c3.x), bf(c3.y), bf(c3.z), x0, y0, x1, y1, flags, ridx, bx, by,
-                               pxlo, pxhi, pylo, pyhi, best_d, best_r, lane_far,
-                               [&]() -> ShadeRec { return prec[ridx].s; }, st);
+      raster_entry<STATS, DBG>(lv, prec, uf(r0.x), uf(r0.y), uf(r0.z), uf(r0.w), uf(r1.x), uf(r1.y), uf(r1.z), uf(r1.w),
+                               uf(r3.x), za, zb, zc, uf(r2.x), uf(r2.y), uf(r2.z), x0, y0, x1, y1, flags, ridx, bx, by, pxlo,
+                               pxhi, pylo, pyhi, best_d, best_r, lane_far, [&]() -> ShadeRec { return prec[ridx].s; }, st);
     }
   }
   if (STATS && lane == 0)
@@ -333,17 +394,18 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
     (void)hipFree(d_stats);
     const double waves = (double)nblocks * 4.0;
     fprintf(stderr,
-            "[rdoom stats] per wave: queue %.1f  quadrant-bbox %.1f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
-            "  general %.2f (lanes %.1f: zrange %.1f, rw<=0 %.1f, masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | coarse tests/block %.0f hits %.1f\n",
-            h[0] / waves, h[1] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
+            "[rdoom stats] per wave: queue %.1f  quadrant-bbox %.1f  quadrant-cover %.2f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
+            "  general %.2f (lanes %.1f: masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | coarse tests/block %.0f hits %.1f\n",
+            h[0] / waves, h[1] / waves, h[10] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
             h[4] ? (double)h[5] / h[4] : 0.0, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
-            h[6] ? (double)h[10] / h[6] : 0.0, h[6] ? (double)h[11] / h[6] : 0.0, h[6] ? (double)h[12] / h[6] : 0.0,
-            h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, (double)h[8] / (double)nblocks,
-            (double)h[9] / (double)nblocks);
+            h[6] ? (double)h[12] / h[6] : 0.0, h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves,
+            (double)h[8] / (double)nblocks, (double)h[9] / (double)nblocks);
   } else {
     static const int raster_dbg = getenv("RDOOM_RASTER_DBG") ? atoi(getenv("RDOOM_RASTER_DBG")) : 0;  // timing experiments
-    auto rk = raster_dbg == 1 ? raster_wave_kernel<false, 1>
-                              : (raster_dbg == 2 ? raster_wave_kernel<false, 2> : raster_wave_kernel<false, 0>);
+    auto rk = raster_dbg == 1   ? raster_wave_kernel<false, 1>
+              : raster_dbg == 2 ? raster_wave_kernel<false, 2>
+              : raster_dbg == 3 ? raster_wave_kernel<false, 3>
+                                : raster_wave_kernel<false, 0>;
     hipLaunchKernelGGL(rk, dim3((uint32_t)nblocks), dim3(256), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
                        tiles_y, tile_hdr, entries, entry_cap, overflow, vis, vis16 ? 1u : 0u, prim_out,
                        (unsigned long long *)nullptr);
