@@ -114,14 +114,14 @@ __device__ __forceinline__ void raster_entry(const DeviceLevelView &lv, const Tr
 #pragma unroll
         for (int ry = 0; ry < 4; ry++) {
           const int iy = by + ry;
-          const float py = (float)iy + 0.5f;
+          const float py = pylo + (float)ry;  // == (float)iy + 0.5f exactly
           const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
           const float tz = fmaf(zb, py, zc), tw = fmaf(wb, py, wc);
           const bool rowin = iy >= y0 && iy <= y1;
 #pragma unroll
           for (int rx = 0; rx < 4; rx++) {
             const int ix = bx + rx;
-            const float px = (float)ix + 0.5f;
+            const float px = pxlo + (float)rx;  // == (float)ix + 0.5f exactly
             const float e0 = fmaf(e0a, px, t0), e1 = fmaf(e1a, px, t1), e2 = fmaf(e2a, px, t2);
             const bool in0 = (e0 > 0.0f) | ((e0 == 0.0f) & ((flags & (1u << 24)) != 0u));
             const bool in1 = (e1 > 0.0f) | ((e1 == 0.0f) & ((flags & (1u << 25)) != 0u));
@@ -164,18 +164,21 @@ __device__ __forceinline__ void raster_entry(const DeviceLevelView &lv, const Tr
 }
 
 // =================================================================================================
-// Kernel 2: tiled rasteriser, wave-autonomous.  One 256-thread workgroup per (pose, 64x64 tile); each wavefront
-// owns a 32x32 quadrant and runs on its own (no LDS staging of records, no workgroup barriers); each lane owns a
-// 4x4 pixel block whose depth / winner live in registers.  blockIdx -> (pose, tile) keeps all tiles of a pose on
-// one XCD (b % 8): its records stay in that XCD's L2.
-//   * candidates  64 tile-list entries at a time, one per lane; the lanes whose entry touches this wave's
-//                 quadrant are ranked by record index (= depth rank) with readlane broadcasts and compacted
-//                 through a 256-byte per-wave LDS scratch;
-//   * records     lane s gathers the 80-byte raster record of the s-th entry straight into registers and
-//                 computes, for all entries at once, the nearest depth of the triangle over the quadrant;
-//   * walk        entry s is broadcast with v_readlane: its coefficients become wave-uniform SGPR operands.
-//                 One compare against the lanes' farthest depths skips a hidden triangle before anything
-//                 else is touched (most rejections are of this kind).
+// Kernel 2: tiled rasteriser, wave-autonomous.  One wavefront per (pose, 64x64 tile), four tiles per 256-thread
+// workgroup, no workgroup barriers.  The wave gathers the tile's list once and then rasterises the tile's four
+// 32x32 quadrants one after the other: in a quadrant each lane owns a 4x4 pixel block whose depth / winner live
+// in registers.  blockIdx -> (pose, tiles) keeps all tiles of a pose on one XCD (b % 8): its records stay in that
+// XCD's L2.
+//   * candidates  64 tile-list entries at a time, one per lane, ranked by record index (= depth rank) with
+//                 readlane broadcasts and compacted through a 256-byte per-wave LDS scratch;
+//   * records     lane s gathers the 80-byte raster record of the s-th entry, parks 15 of its words in LDS and
+//                 computes, for all four quadrants at once, the nearest depth of the triangle over the quadrant
+//                 and whether the triangle covers the quadrant entirely (exact corner arguments);
+//   * walk        per quadrant, entry s is broadcast with v_readlane / uniform LDS reads: its coefficients become
+//                 wave-uniform SGPR operands.  One compare against the lanes' farthest depths skips a hidden
+//                 triangle before anything else is touched (most rejections are of this kind); a covering
+//                 triangle runs a depth-only pixel body.
+// A tile with more than 64 entries re-gathers each 64-entry batch once per quadrant.
 // =================================================================================================
 template <bool STATS, int DBG = 0>  // DBG: timing experiments only (1 = no queue walk, 2 = reject tests but no pixel bodies, 3 = no quadrant-cover path)
 __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
@@ -192,185 +195,205 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
   __shared__ uint32_t wq[4][64];
   __shared__ uint4 wrec[4][64][4];  // per wave: 15 words of each of the 64 gathered raster records
   const uint32_t b = blockIdx.x;
-  const uint32_t T = (uint32_t)(tiles_x * tiles_y);
+  const uint32_t T = (uint32_t)(tiles_x * tiles_y), T4 = (T + 3u) >> 2;
   const uint32_t g = b >> 3;
-  const uint32_t pose = (g / T) * 8u + (b & 7u);
-  const uint32_t tile = g % T;
-  if (pose >= n_poses) return;
-  const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE_W, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE_H;
+  const uint32_t pose = (g / T4) * 8u + (b & 7u);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave: an SGPR
-  const int qx0 = tx0 + (wave & 1) * 32, qy0 = ty0 + (wave >> 1) * 32;  // this wave's quadrant
-  const int bx = qx0 + (lane & 7) * 4, by = qy0 + (lane >> 3) * 4;      // this lane's 4x4 block
-  const float pxlo = (float)bx + 0.5f, pxhi = (float)bx + 3.5f, pylo = (float)by + 0.5f, pyhi = (float)by + 3.5f;
-  const float qxl = (float)qx0 + 0.5f, qxh = (float)qx0 + 31.5f, qyl = (float)qy0 + 0.5f, qyh = (float)qy0 + 31.5f;
-  uint32_t best_d[16], best_r[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    best_d[k] = NONE;
-    best_r[k] = NONE;
-  }
-  uint32_t lane_far = NONE;  // max of best_d: the farthest depth this lane still holds
+  const uint32_t tile = (g % T4) * 4u + (uint32_t)wave;
+  if (pose >= n_poses || tile >= T) return;
+  const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE_W, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE_H;
+  const int lx = (lane & 7) * 4, ly = (lane >> 3) * 4;  // this lane's 4x4 block inside a quadrant
   const TriRec *prec = recs + (size_t)pose * cap;
   const uint4 *psorted = sorted + (size_t)pose * cap;
   const bool binned = overflow[pose] == 0u;  // the pose's per-tile lists are complete
   const uint2 hdr = binned ? tile_hdr[(size_t)pose * T + tile] : make_uint2(0u, counts[pose]);
   const uint32_t *pent = entries + (size_t)pose * entry_cap + hdr.x;
   const uint32_t count = DBG == 1 ? 0u : hdr.y;
+  const bool single = count <= 64u;  // the usual case: one gather serves all four quadrants
   uint32_t *myq = wq[wave];
-  for (uint32_t base = 0; base < count; base += 64u) {
-    // ---- candidates: one per lane ------------------------------------------------------------------
-    const uint32_t i = base + (uint32_t)lane;
-    uint32_t cand = 0;
-    bool rel = false;
-    if (i < count) {
-      if (binned) {
-        const uint32_t e = pent[i];
-        cand = e & 0x0FFFFFFFu;
-        rel = ((e >> (28 + wave)) & 1u) != 0u;  // exact quadrant test done by the binning kernel
-      } else {
-        // pose without complete bins: every visible triangle is a candidate; bbox, then the exact quadrant test
-        const uint4 bb = psorted[i];  // (bb0, bb1, record index, depth bucket), near to far
-        cand = bb.z;
-        const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
-        if (x0 <= qx0 + 31 && x1 >= qx0 && y0 <= qy0 + 31 && y1 >= qy0) {
-          const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[cand]);
-          // (rare path: the barrier keeps the compiler from hoisting its vectorised corner constants out of the
-          // loop, where they would cost the hot path registers)
-          float lxl = qxl, lxh = qxh, lyl = qyl, lyh = qyh;
-          asm volatile("" : "+v"(lxl), "+v"(lxh), "+v"(lyl), "+v"(lyh));
-          rel = rect_may_touch(rp[0], rp[1], rp[2], lxl, lxh, lyl, lyh);
-        }
-      }
-    }
-    if (STATS && !binned) st[8] += (unsigned long long)__popcll(__ballot(i < count)), st[9] += (unsigned long long)__popcll(__ballot(rel));
-    const unsigned long long rm = __ballot(rel);
-    const uint32_t n = (uint32_t)__popcll(rm);
-    if (n == 0u) continue;
-    // rank of my entry among the relevant ones (record index = depth rank; the lists are near-sorted already)
-    uint32_t rank = 0;
-    for (unsigned long long m = rm; m; m &= m - 1ull) {
-      const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(m));
-      rank += kj < cand ? 1u : 0u;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier readers of myq are done
-    if (rel) myq[rank] = cand;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // ---- records: lane s gathers entry s ------------------------------------------------------------
-    const bool have = (uint32_t)lane < n;
-    const uint32_t myrec = have ? myq[lane] : 0u;
-    // nearest depth of my entry's plane over the quadrant (exact corner argument), as d24; none if beyond far;
-    // and whether my entry covers the whole quadrant, so that its pixels need depth compares only (same argument:
-    // the smallest computed value of each edge function, of the depth and of 1/w over the quadrant sits at a corner).
-    // Only the depth plane stays in registers; the rest of the record waits in LDS for the entries that need it.
-    uint32_t dnq = NONE, zpa = 0u, zpb = 0u, zpc = 0u;
-    bool qcov = false;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier readers of mine are done
-    if (have) {
-      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[myrec]);
-      const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3];
-      const uint2 c4 = *reinterpret_cast<const uint2 *>(rp + 4);
-      uint4 *mine = wrec[wave][lane];
-      mine[0] = c0, mine[1] = c1, mine[2] = c3, mine[3] = make_uint4(c2.x, c4.x, c4.y, 0u);
-      zpa = c2.y, zpb = c2.z, zpc = c2.w;
-      const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
-                  e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
-                  e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x);
-      const float za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
-      const float wa = __uint_as_float(c3.x), wb = __uint_as_float(c3.y), wc = __uint_as_float(c3.z);
-      const float zn = fmaf(za, pos(za) ? qxl : qxh, fmaf(zb, pos(zb) ? qyl : qyh, zc));
-      const float zf = fmaf(za, pos(za) ? qxh : qxl, fmaf(zb, pos(zb) ? qyh : qyl, zc));
-      if (zn <= 1.0f) dnq = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
-      const float n0 = fmaf(e0a, pos(e0a) ? qxl : qxh, fmaf(e0b, pos(e0b) ? qyl : qyh, e0c));
-      const float n1 = fmaf(e1a, pos(e1a) ? qxl : qxh, fmaf(e1b, pos(e1b) ? qyl : qyh, e1c));
-      const float n2 = fmaf(e2a, pos(e2a) ? qxl : qxh, fmaf(e2b, pos(e2b) ? qyl : qyh, e2c));
-      const float rwn = fmaf(wa, pos(wa) ? qxl : qxh, fmaf(wb, pos(wb) ? qyl : qyh, wc));
-      const int x0 = (int)(c3.w & 0xFFFFu), y0 = (int)(c3.w >> 16), x1 = (int)(c4.x & 0xFFFFu), y1 = (int)(c4.x >> 16);
-      qcov = (n0 > 0.0f) & (n1 > 0.0f) & (n2 > 0.0f) & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) & (x0 <= qx0) &
-             (x1 >= qx0 + 31) & (y0 <= qy0) & (y1 >= qy0 + 31) & ((c4.y & RASTER_MASKED_INTERIOR) == 0u);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const unsigned long long qcm = DBG == 3 ? 0ull : __ballot(qcov);
-    // ---- walk ------------------------------------------------------------------------------------------
-    for (uint32_t s = 0; s < n; s++) {
-      if (STATS) st[0]++;
-      const uint32_t dq = (uint32_t)__builtin_amdgcn_readlane((int)dnq, (int)s);
-      // hidden in the whole quadrant: every lane's nearest depth is >= dq (its block lies inside the quadrant)
-      if (!__any(dq <= lane_far)) {
-        if (STATS) st[15]++;
-        continue;
-      }
-      if (STATS) st[1]++;
-      auto bc = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)s); };
-      auto bf = [&](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, (int)s)); };
-      const float za = bf(zpa), zb = bf(zpb), zc = bf(zpc);
-      const uint32_t ridx = bc(myrec);
-      if ((qcm >> s) & 1ull) {
-        // the triangle covers the whole quadrant, inside its bbox, the depth range and in front of the eye, texture
-        // rectangle opaque: depth compares only.  (Lanes whose block is hidden lose every compare.)  A depth tie is
-        // replayed through the regular path below, which re-resolves the block exactly.
-        if (STATS) st[10]++;
-        if (DBG == 2) {
-          best_r[0] = ridx;
-          continue;
-        }
-        bool tie = false, updated = false;
+  // what lane s keeps of the s-th entry of the current batch: record index, quadrant bits (touches: 0..3, covers:
+  // 4..7), the depth plane, the nearest depth over each quadrant
+  uint32_t n = 0, myrec = 0, myqb = 0, zpa = 0, zpb = 0, zpc = 0, dnq0 = NONE, dnq1 = NONE, dnq2 = NONE, dnq3 = NONE;
+#pragma unroll 1
+  for (int q = 0; q < 4; q++) {
+    const int qx0 = tx0 + (q & 1) * 32, qy0 = ty0 + (q >> 1) * 32;  // this quadrant
+    const int bx = qx0 + lx, by = qy0 + ly;                         // this lane's 4x4 block
+    const float pxlo = (float)bx + 0.5f, pxhi = (float)bx + 3.5f, pylo = (float)by + 0.5f, pyhi = (float)by + 3.5f;
+    uint32_t best_d[16], best_r[16];
 #pragma unroll
-        for (int ry = 0; ry < 4; ry++) {
-          const float tz = fmaf(zb, pylo + (float)ry, zc);
-#pragma unroll
-          for (int rx = 0; rx < 4; rx++) {
-            const int k = ry * 4 + rx;
-            const uint32_t d24 = __float2uint_rz(fmaf(fmaf(za, pxlo + (float)rx, tz), 16777215.0f, 0.5f));
-            const bool win = d24 < best_d[k];
-            tie |= d24 == best_d[k];
-            best_d[k] = win ? d24 : best_d[k];
-            best_r[k] = win ? ridx : best_r[k];
-            updated |= win;
+    for (int k = 0; k < 16; k++) {
+      best_d[k] = NONE;
+      best_r[k] = NONE;
+    }
+    uint32_t lane_far = NONE;  // max of best_d: the farthest depth this lane still holds
+#pragma unroll 1
+    for (uint32_t base = 0; base < count; base += 64u) {
+      if (!single || q == 0) {
+        // ---- candidates: one per lane ----------------------------------------------------------------
+        const uint32_t i = base + (uint32_t)lane;
+        uint32_t cand = 0, qb = 0;
+        if (i < count) {
+          if (binned) {
+            const uint32_t e = pent[i];
+            cand = e & 0x0FFFFFFFu;
+            qb = e >> 28;  // exact quadrant tests done by the binning kernel
+          } else {
+            // pose without complete bins: every visible triangle is a candidate; bbox, then the exact quadrant tests
+            const uint4 bb = psorted[i];  // (bb0, bb1, record index, depth bucket), near to far
+            cand = bb.z;
+            const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
+            if (x0 <= tx0 + 63 && x1 >= tx0 && y0 <= ty0 + 63 && y1 >= ty0) {
+              const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[cand]);
+              qb = tile_quadrant_mask(rp[0], rp[1], rp[2], x0, y0, x1, y1, tx0, ty0);
+            }
           }
         }
-        if (updated) {
-          uint32_t m = best_d[0];
+        if (STATS && !binned) st[8] += (unsigned long long)__popcll(__ballot(i < count)), st[9] += (unsigned long long)__popcll(__ballot(qb != 0u));
+        const unsigned long long rm = __ballot(qb != 0u);
+        n = (uint32_t)__popcll(rm);
+        if (n != 0u) {
+          // rank of my entry among the relevant ones (record index = depth rank; the lists are near-sorted already)
+          uint32_t rank = 0;
+          for (unsigned long long m = rm; m; m &= m - 1ull) {
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(m));
+            rank += kj < cand ? 1u : 0u;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier readers of myq / wrec are done
+          if (qb != 0u) myq[rank] = cand | (qb << 28);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          // ---- records: lane s gathers entry s -------------------------------------------------------
+          const bool have = (uint32_t)lane < n;
+          myrec = 0u, myqb = 0u, zpa = zpb = zpc = 0u, dnq0 = dnq1 = dnq2 = dnq3 = NONE;
+          if (have) {
+            const uint32_t e = myq[lane];
+            myrec = e & 0x0FFFFFFFu;
+            myqb = e >> 28;
+            const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[myrec]);
+            const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3];
+            const uint2 c4 = *reinterpret_cast<const uint2 *>(rp + 4);
+            uint4 *mine = wrec[wave][lane];
+            mine[0] = c0, mine[1] = c1, mine[2] = c3, mine[3] = make_uint4(c2.x, c4.x, c4.y, 0u);
+            zpa = c2.y, zpb = c2.z, zpc = c2.w;
+            // per quadrant: nearest depth of my entry's plane over it as d24 (none if beyond far), and whether my
+            // entry covers it entirely -- the smallest computed value of each edge function and of 1/w and the
+            // extremes of the depth over the quadrant sit at corners (fmaf is monotone in each argument)
+            const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
+                        e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
+                        e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x);
+            const float za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
+            const float wa = __uint_as_float(c3.x), wb = __uint_as_float(c3.y), wc = __uint_as_float(c3.z);
+            const int x0 = (int)(c3.w & 0xFFFFu), y0 = (int)(c3.w >> 16), x1 = (int)(c4.x & 0xFFFFu), y1 = (int)(c4.x >> 16);
+            uint32_t dn[4];
 #pragma unroll
-          for (int k = 1; k < 16; k++) m = max(m, best_d[k]);
-          lane_far = m;
+            for (int qi = 0; qi < 4; qi++) {
+              const int rx0 = tx0 + (qi & 1) * 32, ry0 = ty0 + (qi >> 1) * 32;
+              const float xl = (float)rx0 + 0.5f, xh = (float)rx0 + 31.5f, yl = (float)ry0 + 0.5f, yh = (float)ry0 + 31.5f;
+              const float zn = fmaf(za, pos(za) ? xl : xh, fmaf(zb, pos(zb) ? yl : yh, zc));
+              const float zf = fmaf(za, pos(za) ? xh : xl, fmaf(zb, pos(zb) ? yh : yl, zc));
+              dn[qi] = zn <= 1.0f ? __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f)) : NONE;
+              const float n0 = fmaf(e0a, pos(e0a) ? xl : xh, fmaf(e0b, pos(e0b) ? yl : yh, e0c));
+              const float n1 = fmaf(e1a, pos(e1a) ? xl : xh, fmaf(e1b, pos(e1b) ? yl : yh, e1c));
+              const float n2 = fmaf(e2a, pos(e2a) ? xl : xh, fmaf(e2b, pos(e2b) ? yl : yh, e2c));
+              const float rwn = fmaf(wa, pos(wa) ? xl : xh, fmaf(wb, pos(wb) ? yl : yh, wc));
+              const bool cov = (n0 > 0.0f) & (n1 > 0.0f) & (n2 > 0.0f) & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) &
+                               (x0 <= rx0) & (x1 >= rx0 + 31) & (y0 <= ry0) & (y1 >= ry0 + 31) &
+                               ((c4.y & RASTER_MASKED_INTERIOR) == 0u);
+              myqb |= (cov && DBG != 3) ? (16u << qi) : 0u;
+            }
+            dnq0 = dn[0], dnq1 = dn[1], dnq2 = dn[2], dnq3 = dn[3];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        if (!__any(tie)) continue;
       }
-      // the rest of the record: uniform LDS reads, made SGPR operands
-      const uint4 *wr = wrec[wave][s];
-      const uint4 r0 = wr[0], r1 = wr[1], r2 = wr[2], r3 = wr[3];
-      auto uf = [](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)v)); };
-      auto uu = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-      const uint32_t bb0 = uu(r2.w), bb1 = uu(r3.y), flags = uu(r3.z);
-      const int x0 = (int)(bb0 & 0xFFFFu), y0 = (int)(bb0 >> 16), x1 = (int)(bb1 & 0xFFFFu), y1 = (int)(bb1 >> 16);
-      raster_entry<STATS, DBG>(lv, prec, uf(r0.x), uf(r0.y), uf(r0.z), uf(r0.w), uf(r1.x), uf(r1.y), uf(r1.z), uf(r1.w),
-                               uf(r3.x), za, zb, zc, uf(r2.x), uf(r2.y), uf(r2.z), x0, y0, x1, y1, flags, ridx, bx, by, pxlo,
-                               pxhi, pylo, pyhi, best_d, best_r, lane_far, [&]() -> ShadeRec { return prec[ridx].s; }, st);
+      if (n == 0u) continue;
+      // ---- walk: the entries that touch this quadrant, near to far -------------------------------------------
+      const uint32_t dnq = q == 0 ? dnq0 : (q == 1 ? dnq1 : (q == 2 ? dnq2 : dnq3));
+      const unsigned long long qcm = __ballot(((myqb >> (4 + q)) & 1u) != 0u);
+      for (unsigned long long wm = __ballot(((myqb >> q) & 1u) != 0u); wm; wm &= wm - 1ull) {
+        const uint32_t s = (uint32_t)__builtin_ctzll(wm);
+        if (STATS) st[0]++;
+        const uint32_t dq = (uint32_t)__builtin_amdgcn_readlane((int)dnq, (int)s);
+        // hidden in the whole quadrant: every lane's nearest depth is >= dq (its block lies inside the quadrant)
+        if (!__any(dq <= lane_far)) {
+          if (STATS) st[15]++;
+          continue;
+        }
+        if (STATS) st[1]++;
+        auto bc = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)s); };
+        auto bf = [&](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, (int)s)); };
+        const float za = bf(zpa), zb = bf(zpb), zc = bf(zpc);
+        const uint32_t ridx = bc(myrec);
+        if ((qcm >> s) & 1ull) {
+          // the triangle covers the whole quadrant, inside its bbox, the depth range and in front of the eye, texture
+          // rectangle opaque: depth compares only.  (Lanes whose block is hidden lose every compare.)  A depth tie
+          // is replayed through the regular path below, which re-resolves the block exactly.
+          if (STATS) st[10]++;
+          if (DBG == 2) {
+            best_r[0] = ridx;
+            continue;
+          }
+          bool tie = false, updated = false;
+#pragma unroll
+          for (int ry = 0; ry < 4; ry++) {
+            const float tz = fmaf(zb, pylo + (float)ry, zc);
+#pragma unroll
+            for (int rx = 0; rx < 4; rx++) {
+              const int k = ry * 4 + rx;
+              const uint32_t d24 = __float2uint_rz(fmaf(fmaf(za, pxlo + (float)rx, tz), 16777215.0f, 0.5f));
+              const bool win = d24 < best_d[k];
+              tie |= d24 == best_d[k];
+              best_d[k] = win ? d24 : best_d[k];
+              best_r[k] = win ? ridx : best_r[k];
+              updated |= win;
+            }
+          }
+          if (updated) {
+            uint32_t m = best_d[0];
+#pragma unroll
+            for (int k = 1; k < 16; k++) m = max(m, best_d[k]);
+            lane_far = m;
+          }
+          if (!__any(tie)) continue;
+        }
+        // the rest of the record: uniform LDS reads, made SGPR operands
+        const uint4 *wr = wrec[wave][s];
+        const uint4 r0 = wr[0], r1 = wr[1], r2 = wr[2], r3 = wr[3];
+        auto uf = [](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)v)); };
+        auto uu = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+        const uint32_t bb0 = uu(r2.w), bb1 = uu(r3.y), flags = uu(r3.z);
+        const int x0 = (int)(bb0 & 0xFFFFu), y0 = (int)(bb0 >> 16), x1 = (int)(bb1 & 0xFFFFu), y1 = (int)(bb1 >> 16);
+        raster_entry<STATS, DBG>(lv, prec, uf(r0.x), uf(r0.y), uf(r0.z), uf(r0.w), uf(r1.x), uf(r1.y), uf(r1.z), uf(r1.w),
+                                 uf(r3.x), za, zb, zc, uf(r2.x), uf(r2.y), uf(r2.z), x0, y0, x1, y1, flags, ridx, bx, by, pxlo,
+                                 pxhi, pylo, pyhi, best_d, best_r, lane_far, [&]() -> ShadeRec { return prec[ridx].s; }, st);
+      }
+    }
+    // ---- this quadrant's visibility words ------------------------------------------------------------------------
+    if (bx < width) {
+      const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
+#pragma unroll
+      for (int ry = 0; ry < 4; ry++) {
+        if (by + ry < height) {
+          const size_t o = o0 + (size_t)(ry * width);
+          if (vis16)  // record indices fit 16 bits (0xFFFF = none): half the visibility traffic
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) =
+                make_uint2(__builtin_amdgcn_perm(best_r[ry * 4 + 1], best_r[ry * 4], 0x05040100u),
+                           __builtin_amdgcn_perm(best_r[ry * 4 + 3], best_r[ry * 4 + 2], 0x05040100u));
+          else
+            *reinterpret_cast<uint4 *>(vis + o) =
+                make_uint4(best_r[ry * 4], best_r[ry * 4 + 1], best_r[ry * 4 + 2], best_r[ry * 4 + 3]);
+          if (prim_out) {
+            uint32_t p[4];
+#pragma unroll
+            for (int rx = 0; rx < 4; rx++)
+              p[rx] = best_r[ry * 4 + rx] == NONE ? NONE : (prec[best_r[ry * 4 + rx]].r.flags & 0xFFFFFFu);
+            *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p[0], p[1], p[2], p[3]);
+          }
+        }
+      }
     }
   }
   if (STATS && lane == 0)
     for (int k = 0; k < 16; k++) atomicAdd(&stats[k], st[k]);
-#pragma unroll
-  for (int ry = 0; ry < 4; ry++) {
-    const int iy = by + ry;
-    if (iy < height && bx < width) {
-      const size_t o = ((size_t)pose * (size_t)height + (size_t)iy) * (size_t)width + (size_t)bx;
-      if (vis16)  // record indices fit 16 bits (0xFFFF = none): half the visibility traffic
-        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) =
-            make_uint2((best_r[ry * 4] & 0xFFFFu) | (best_r[ry * 4 + 1] << 16),
-                       (best_r[ry * 4 + 2] & 0xFFFFu) | (best_r[ry * 4 + 3] << 16));
-      else
-        *reinterpret_cast<uint4 *>(vis + o) =
-            make_uint4(best_r[ry * 4], best_r[ry * 4 + 1], best_r[ry * 4 + 2], best_r[ry * 4 + 3]);
-      if (prim_out) {
-        uint32_t p[4];
-#pragma unroll
-        for (int rx = 0; rx < 4; rx++)
-          p[rx] = best_r[ry * 4 + rx] == NONE ? NONE : (prec[best_r[ry * 4 + rx]].r.flags & 0xFFFFFFu);
-        *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p[0], p[1], p[2], p[3]);
-      }
-    }
-  }
 }
 
 }  // namespace
@@ -380,7 +403,7 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
                            const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out) {
   const uint32_t n = n_poses;
-  const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)(tiles_x * tiles_y);
+  const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)((tiles_x * tiles_y + 3) / 4);  // four tiles per workgroup
   if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
   static const bool want_stats = getenv("RDOOM_STATS") != nullptr;
   if (want_stats) {
@@ -392,7 +415,7 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
                        prim_out, d_stats);
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     (void)hipFree(d_stats);
-    const double waves = (double)nblocks * 4.0;
+    const double waves = (double)((n + 7) / 8) * 8.0 * (double)(tiles_x * tiles_y) * 4.0;  // (pose, quadrant) passes
     fprintf(stderr,
             "[rdoom stats] per wave: queue %.1f  quadrant-bbox %.1f  quadrant-cover %.2f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
             "  general %.2f (lanes %.1f: masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | coarse tests/block %.0f hits %.1f\n",
