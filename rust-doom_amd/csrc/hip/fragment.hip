@@ -161,39 +161,36 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
     if (ui - lane >= units_per_pose) break;  // wave-uniform: the whole wave is past the end of the frame
     const bool valid = ui < units_per_pose;
     const uint32_t q0 = ui * (uint32_t)NQ;
-    // visibility words of my NPX pixels
-    uint32_t id[NPX];
-#pragma unroll
-    for (int k = 0; k < NPX; k++) id[k] = NONE_ID;
+    // visibility words of my NPX pixels: all the same?  (compared as loaded, two 16-bit words at a time)
+    uint32_t id0 = NONE_ID;
+    bool uniform = true;
     if (valid) {
       if (VIS16) {
         if (NQ == 2) {
           const uint4 v = *reinterpret_cast<const uint4 *>(pvis16 + (size_t)q0 * 4u);
-          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int k = 0; k < NPX; k++) id[k] = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu);
+          id0 = v.x & 0xFFFFu;
+          uniform = (v.x == __builtin_amdgcn_alignbit(v.x, v.x, 16)) & (v.x == v.y) & (v.y == v.z) & (v.z == v.w);
         } else {
           const uint2 v = *reinterpret_cast<const uint2 *>(pvis16 + (size_t)q0 * 4u);
-          id[0] = v.x & 0xFFFFu, id[1] = v.x >> 16, id[2] = v.y & 0xFFFFu, id[3] = v.y >> 16;
+          id0 = v.x & 0xFFFFu;
+          uniform = (v.x == __builtin_amdgcn_alignbit(v.x, v.x, 16)) & (v.x == v.y);
         }
       } else {
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
           const uint4 v = *reinterpret_cast<const uint4 *>(pvis32 + ((size_t)q0 + (size_t)q) * 4u);
-          id[4 * q] = v.x, id[4 * q + 1] = v.y, id[4 * q + 2] = v.z, id[4 * q + 3] = v.w;
+          if (q == 0) id0 = v.x;
+          uniform &= (v.x == id0) & (v.y == id0) & (v.z == id0) & (v.w == id0);
         }
       }
     }
-    bool uniform = true;
-#pragma unroll
-    for (int k = 1; k < NPX; k++) uniform &= id[k] == id[0];
     bool done = false;
     uint32_t out[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) out[q] = 0;
-    if (uniform & (id[0] == NONE_ID)) done = true;  // background (or past the end: nothing is stored)
-    if (uniform & (id[0] != NONE_ID) & (debug_leak_mod == 0u)) {
-      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[id[0]].s);
+    if (uniform & (id0 == NONE_ID)) done = true;  // background (or past the end: nothing is stored)
+    if (uniform & (id0 != NONE_ID) & (debug_leak_mod == 0u)) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[id0].s);
       const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
       const uint32_t flags = r3.z, tex = r3.w;
       // (all four loads are issued before the flag is examined: one memory latency, not two)
@@ -211,7 +208,11 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
         // F2 preparation: q0 = t * RN(1/size) equals the quotient exactly for a power-of-two size; for an integer
         // size it is within |t/size| * 2^-23 of it, and the remainder test below certifies
         // floor(q0) == floor(RN(t / size)) (else the run goes to the general body).
-        const f32x2 inv_s = exact_rcp2(f32x2{size_x, size_y});
+        // (1 / 2^k is one integer subtraction on the exponent field; the reciprocal forms only run in waves that hold
+        // a record with an integer, non-power-of-two size)
+        const bool any_np2 = __any((flags & SHADE_NP2) != 0u);
+        f32x2 inv_s = {__uint_as_float(0x7F000000u - __float_as_uint(size_x)), __uint_as_float(0x7F000000u - __float_as_uint(size_y))};
+        if (any_np2) inv_s = exact_rcp2(f32x2{size_x, size_y});
         // F3 parameters: one u16 texel store, REPEAT = masks
         const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
         const uint32_t base2 = base * 2u;  // byte offsets < 2^27: one 32-bit VGPR offset from the uniform base pointer
@@ -223,7 +224,6 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
         // rw > 0, w = 1/rw are monotone along the run (and rounding is monotone).  The run's guard is at least every
         // pixel's own guard, so passing here implies mod_cert() for each pixel -- the form the on-device self-test sweeps.
         // Power-of-two axes always pass.
-        const bool any_np2 = __any((flags & SHADE_NP2) != 0u);
         const bool p2x = (flags & SHADE_POW2_X) != 0u, p2y = (flags & SHADE_POW2_Y) != 0u;
         bool mod_ok = true;
         float lox = 0.0f, hix = 0.0f, loy = 0.0f, hiy = 0.0f;
