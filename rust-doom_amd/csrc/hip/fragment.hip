@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
                                                        uint32_t chunks_per_pose, uint32_t chunk_iters,
                                                        uint32_t quads_per_pose,
                                                        uint32_t quads_per_row, uint32_t div_m, uint32_t div_sh,
+                                                       uint32_t wblocks_per_row, uint32_t wblocks_per_pose,
                                                        int width, int height, const float *__restrict__ ndc_tab,
                                                        uint8_t *__restrict__ fb, uint32_t *__restrict__ fix_count,
                                                        uint2 *__restrict__ fix_list, uint32_t fix_cap,
@@ -155,35 +156,46 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
       if (k == 0) pfb[qi] = v;
     }
   };
-  const uint32_t units_per_pose = quads_per_pose / (uint32_t)NQ;  // a unit = the NQ adjacent quads of one lane
+  // A unit = the NQ adjacent quads of one lane.  A wavefront takes a block of 8 units x 8 rows (64 x 8 pixels for
+  // NQ = 2) per iteration rather than 64 units of one row: the texels (and records) it gathers then come from a compact
+  // patch of texture space -- a few cache lines per load instruction instead of one per lane on floors and ceilings.
+  const uint32_t units_per_row = quads_per_row / (uint32_t)NQ;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   for (uint32_t it = 0; it < chunk_iters; it++) {
-    const uint32_t ui = (chunk * chunk_iters + it) * 256u + threadIdx.x;
-    if (ui - lane >= units_per_pose) break;  // wave-uniform: the whole wave is past the end of the frame
-    const bool valid = ui < units_per_pose;
-    const uint32_t q0 = ui * (uint32_t)NQ;
-    // visibility words of my NPX pixels: all the same?  (compared as loaded, two 16-bit words at a time)
-    uint32_t id0 = NONE_ID;
-    bool uniform = true;
-    if (valid) {
-      if (VIS16) {
-        if (NQ == 2) {
-          const uint4 v = *reinterpret_cast<const uint4 *>(pvis16 + (size_t)q0 * 4u);
-          id0 = v.x & 0xFFFFu;
-          uniform = (v.x == __builtin_amdgcn_alignbit(v.x, v.x, 16)) & (v.x == v.y) & (v.y == v.z) & (v.z == v.w);
-        } else {
-          const uint2 v = *reinterpret_cast<const uint2 *>(pvis16 + (size_t)q0 * 4u);
-          id0 = v.x & 0xFFFFu;
-          uniform = (v.x == __builtin_amdgcn_alignbit(v.x, v.x, 16)) & (v.x == v.y);
-        }
+    const uint32_t wb = (chunk * chunk_iters + it) * 4u + wave;
+    if (wb >= wblocks_per_pose) break;  // wave-uniform: past the end of the frame
+    const uint32_t wby = wb / wblocks_per_row, wbx = wb - wby * wblocks_per_row;
+    const uint32_t col = wbx * 8u + (lane & 7u), row = wby * 8u + (lane >> 3);
+    const bool valid = (col < units_per_row) & (row < (uint32_t)height);
+    const uint32_t qx = col * (uint32_t)NQ;
+    const uint32_t q0 = row * quads_per_row + qx;
+    // visibility words of my NPX pixels: all the same?  (compared as loaded, two 16-bit words at a time; a lane outside
+    // the frame reads unit 0 and is treated as background -- no divergent branch, no boolean phi)
+    const size_t q0l = valid ? (size_t)q0 : (size_t)0;
+    uint32_t id0;
+    bool uniform;
+    if (VIS16) {
+      if (NQ == 2) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(pvis16 + q0l * 4u);
+        id0 = v.x & 0xFFFFu;
+        uniform = (((v.x ^ __builtin_amdgcn_alignbit(v.x, v.x, 16)) | (v.x ^ v.y)) | ((v.y ^ v.z) | (v.z ^ v.w))) == 0u;
       } else {
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const uint4 v = *reinterpret_cast<const uint4 *>(pvis32 + ((size_t)q0 + (size_t)q) * 4u);
-          if (q == 0) id0 = v.x;
-          uniform &= (v.x == id0) & (v.y == id0) & (v.z == id0) & (v.w == id0);
-        }
+        const uint2 v = *reinterpret_cast<const uint2 *>(pvis16 + q0l * 4u);
+        id0 = v.x & 0xFFFFu;
+        uniform = ((v.x ^ __builtin_amdgcn_alignbit(v.x, v.x, 16)) | (v.x ^ v.y)) == 0u;
       }
+    } else {
+      const uint4 v = *reinterpret_cast<const uint4 *>(pvis32 + q0l * 4u);
+      id0 = v.x;
+      uint32_t diff = (v.x ^ v.y) | (v.y ^ v.z) | (v.z ^ v.w);
+      if (NQ == 2) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(pvis32 + (q0l + 1u) * 4u);
+        diff |= (w.x ^ id0) | (w.x ^ w.y) | (w.y ^ w.z) | (w.z ^ w.w);
+      }
+      uniform = diff == 0u;
     }
+    id0 = valid ? id0 : NONE_ID;
+    uniform |= !valid;
     bool done = false;
     uint32_t out[NQ];
 #pragma unroll
@@ -201,7 +213,6 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
                     va = __uint_as_float(r1.z), vb = __uint_as_float(r1.w), vc = __uint_as_float(r2.x),
                     atlas_u = __uint_as_float(r2.y), atlas_v = __uint_as_float(r2.z), size_x = __uint_as_float(r2.w),
                     size_y = __uint_as_float(r3.x), light = __uint_as_float(r3.y);
-        const uint32_t row = fast_div(q0, div_m, div_sh), qx = q0 - row * quads_per_row;
         const float py = (float)row + 0.5f;
         const float px0 = (float)(qx * 4u) + 0.5f;
         const float row_w = fmaf(wb, py, wc), row_u = fmaf(ub, py, uc), row_v = fmaf(vb, py, vc);
@@ -297,7 +308,6 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
         // a run of sky (sky.frag:12-26): the colour depends on the pixel and the pose only.  ndc_tab holds
         // p / (size / 2) - 1 for every column and row of the frame (computed once per batch with the same two
         // operations), the record carries v_r.y and 4 v_r.x / 3.14159265358; the row part is evaluated once per run.
-        const uint32_t row = fast_div(q0, div_m, div_sh), qx = q0 - row * quads_per_row;
         const float ushift = __uint_as_float(r2.w), vr1 = __uint_as_float(r2.z), band = lv.sky_band;
         float uvy = (-ndc_tab[(uint32_t)width + row] + 1.0f) + vr1;
         if (uvy < 0.0f) {
@@ -475,10 +485,10 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
   static const int frag_nq_env = getenv("RDOOM_FRAG_NQ") ? atoi(getenv("RDOOM_FRAG_NQ")) : 2;  // tuning switch / tests
   static const int frag_dbg = getenv("RDOOM_FRAG_DBG") ? atoi(getenv("RDOOM_FRAG_DBG")) : 0;  // timing experiments (wrong images)
   const int nq = (frag_nq_env == 2 && W % 8 == 0) ? 2 : 1;  // quads per lane: two when rows divide into 8-pixel runs
-  const uint32_t units = qpp / (uint32_t)nq;
+  const uint32_t wbpr = (qpr / (uint32_t)nq + 7u) / 8u, wbpp = wbpr * (((uint32_t)H + 7u) / 8u);  // 8-unit x 8-row blocks
   static const uint32_t frag_chunk =
       getenv("RDOOM_FRAG_CHUNK") ? (uint32_t)std::max(1, atoi(getenv("RDOOM_FRAG_CHUNK"))) : (uint32_t)FRAG_CHUNK;  // tuning switch
-  const uint32_t fblocks = (units + frag_chunk * 256 - 1) / (frag_chunk * 256);
+  const uint32_t fblocks = (wbpp + frag_chunk * 4u - 1u) / (frag_chunk * 4u);  // a workgroup = 4 waves x frag_chunk blocks
   HIP_TRY(hipMemsetAsync(fix_count, 0, 2 * sizeof(uint32_t), st));
   const uint64_t fgrid = (uint64_t)((n + 7) / 8) * 8ull * fblocks;
   if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
@@ -486,7 +496,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
                       : (vis16 ? fragment_kernel<1, 0, true> : fragment_kernel<1, 0, false>);
   if (frag_dbg == 2) frag = vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>;
   hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp,
-                     qpr, div_m, div_sh, W, H, ndc_tab, fb, fix_count, fix_list, fix_cap, debug_leak_mod);
+                     qpr, div_m, div_sh, wbpr, wbpp, W, H, ndc_tab, fb, fix_count, fix_list, fix_cap, debug_leak_mod);
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, H, tiles_x, tiles_y,
                      tile_hdr, entries, entry_cap, overflow, fix_count, fix_list, fix_cap, vis, vis16 ? 1u : 0u, prim_out, fb,
                      fix_count + 1);
