@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
                                                        uint32_t chunks_per_pose, uint32_t chunk_iters,
                                                        uint32_t quads_per_pose,
                                                        uint32_t quads_per_row, uint32_t div_m, uint32_t div_sh,
-                                                       uint32_t wblocks_per_row, uint32_t wblocks_per_pose,
+                                                       uint32_t wblocks_per_row, uint32_t wblocks_per_pose, uint32_t bw_log2,
                                                        int width, int height, const float *__restrict__ ndc_tab,
                                                        uint8_t *__restrict__ fb, uint32_t *__restrict__ fix_count,
                                                        uint2 *__restrict__ fix_list, uint32_t fix_cap,
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
     const uint32_t wb = (chunk * chunk_iters + it) * 4u + wave;
     if (wb >= wblocks_per_pose) break;  // wave-uniform: past the end of the frame
     const uint32_t wby = wb / wblocks_per_row, wbx = wb - wby * wblocks_per_row;
-    const uint32_t col = wbx * 8u + (lane & 7u), row = wby * 8u + (lane >> 3);
+    const uint32_t col = (wbx << bw_log2) + (lane & ((1u << bw_log2) - 1u)), row = (wby << (6u - bw_log2)) + (lane >> bw_log2);
     const bool valid = (col < units_per_row) & (row < (uint32_t)height);
     const uint32_t qx = col * (uint32_t)NQ;
     const uint32_t q0 = row * quads_per_row + qx;
@@ -485,7 +485,9 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
   static const int frag_nq_env = getenv("RDOOM_FRAG_NQ") ? atoi(getenv("RDOOM_FRAG_NQ")) : 2;  // tuning switch / tests
   static const int frag_dbg = getenv("RDOOM_FRAG_DBG") ? atoi(getenv("RDOOM_FRAG_DBG")) : 0;  // timing experiments (wrong images)
   const int nq = (frag_nq_env == 2 && W % 8 == 0) ? 2 : 1;  // quads per lane: two when rows divide into 8-pixel runs
-  const uint32_t wbpr = (qpr / (uint32_t)nq + 7u) / 8u, wbpp = wbpr * (((uint32_t)H + 7u) / 8u);  // 8-unit x 8-row blocks
+  static const uint32_t bwl = getenv("RDOOM_FRAG_BW") ? (uint32_t)std::min(6, std::max(0, atoi(getenv("RDOOM_FRAG_BW")))) : 3u;  // tuning switch: log2(units per block row)
+  const uint32_t bw = 1u << bwl, bh = 64u >> bwl;
+  const uint32_t wbpr = (qpr / (uint32_t)nq + bw - 1u) / bw, wbpp = wbpr * (((uint32_t)H + bh - 1u) / bh);  // bw-unit x bh-row blocks
   static const uint32_t frag_chunk =
       getenv("RDOOM_FRAG_CHUNK") ? (uint32_t)std::max(1, atoi(getenv("RDOOM_FRAG_CHUNK"))) : (uint32_t)FRAG_CHUNK;  // tuning switch
   const uint32_t fblocks = (wbpp + frag_chunk * 4u - 1u) / (frag_chunk * 4u);  // a workgroup = 4 waves x frag_chunk blocks
@@ -496,7 +498,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
                       : (vis16 ? fragment_kernel<1, 0, true> : fragment_kernel<1, 0, false>);
   if (frag_dbg == 2) frag = vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>;
   hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp,
-                     qpr, div_m, div_sh, wbpr, wbpp, W, H, ndc_tab, fb, fix_count, fix_list, fix_cap, debug_leak_mod);
+                     qpr, div_m, div_sh, wbpr, wbpp, bwl, W, H, ndc_tab, fb, fix_count, fix_list, fix_cap, debug_leak_mod);
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, H, tiles_x, tiles_y,
                      tile_hdr, entries, entry_cap, overflow, fix_count, fix_list, fix_cap, vis, vis16 ? 1u : 0u, prim_out, fb,
                      fix_count + 1);
