@@ -496,7 +496,8 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
   if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
   auto frag = nq == 2 ? (vis16 ? fragment_kernel<2, 0, true> : fragment_kernel<2, 0, false>)
                       : (vis16 ? fragment_kernel<1, 0, true> : fragment_kernel<1, 0, false>);
-  if (frag_dbg == 2) frag = vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>;
+  if (frag_dbg == 2) frag = nq == 2 ? (vis16 ? fragment_kernel<2, 2, true> : fragment_kernel<2, 2, false>)
+                               : (vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>);
   hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp,
                      qpr, div_m, div_sh, wbpr, wbpp, bwl, W, H, ndc_tab, fb, fix_count, fix_list, fix_cap, debug_leak_mod);
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, H, tiles_x, tiles_y,
