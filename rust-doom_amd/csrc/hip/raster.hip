@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
     const int qx0 = tx0 + (q & 1) * 32, qy0 = ty0 + (q >> 1) * 32;  // this quadrant
+    if (qx0 >= width || qy0 >= height) continue;                    // entirely outside the frame (partial tiles)
     const int bx = qx0 + lx, by = qy0 + ly;                         // this lane's 4x4 block
     const float pxlo = (float)bx + 0.5f, pxhi = (float)bx + 3.5f, pylo = (float)by + 0.5f, pyhi = (float)by + 3.5f;
     uint32_t best_d[16], best_r[16];
