@@ -40,6 +40,9 @@ namespace {
 // to a per-wave LDS list and shaded afterwards by the general per-pixel body, lane per pixel -- same
 // results, one code path for everything unusual.
 // =================================================================================================
+#ifdef RDOOM_FRAG_STATS  // census build (tools/variant.sh fstats fragment -DRDOOM_FRAG_STATS): where do the runs go?
+__device__ unsigned long long g_frag_stats[16];
+#endif
 constexpr int FRAG_CHUNK = 16;
 constexpr int FRAG_WLIST = 160;  // per-wave list of unfinished quads: at most 15 carried over + 64 x 2 new
 
@@ -68,21 +71,26 @@ __device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const u
 }
 
 // returns the palette index, or 0x100 | index when the winning wall fragment's texel is transparent (the
-// rasteriser treated a border-masked texture as opaque and the coordinate leaked onto the ring)
+// rasteriser treated a border-masked texture as opaque and the coordinate leaked onto the ring).
+// IN_RANGE: the caller guarantees 2^-100 <= rw <= 2^100 (or a sky record): the divisions by rw, dist + 0.9 and dist + 1
+// then take fastmath.hpp's exhaustively verified reciprocal forms -- same bits, a third of the instructions.
+template <bool IN_RANGE>
 __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const uint8_t *cmap, const ShadeRec &s,
                                                 float px, float py, float row_w, float row_u, float row_v,
                                                 int width, int height, const PoseConst &pc) {
   const uint32_t kind = s.flags & 3u;
   if (kind == RDOOM_KIND_SKY) return shade_sky(lv, cmap, px, py, width, height, s.atlas_u, s.atlas_v);
-  const TexelAt t = texel_coords(s, px, row_w, row_u, row_v);
+  const TexelAt t = texel_coords<IN_RANGE>(s, px, row_w, row_u, row_v);
   const uint32_t texel = load_texel(lv, s, t.ix, t.iy);
   if (kind != RDOOM_KIND_FLAT && (texel & 0x8000u)) return 0x100u;
   float light;
   if (kind == RDOOM_KIND_DECOR) {  // sprite.frag:22-25: DIST_SCALE = 1, light = min(v_light, 2 v_light - dist_term)
-    const float dist_term = fminf(1.0f, 1.0f - 1.0f / (t.dist + 1.0f));
+    const float q = IN_RANGE ? exact_rcp(t.dist + 1.0f) : 1.0f / (t.dist + 1.0f);
+    const float dist_term = fminf(1.0f, 1.0f - q);
     light = fminf(s.light, s.light * 2.0f - dist_term);
   } else {
-    const float dist_term = fminf(1.0f, 1.0f - 0.9f / (t.dist + 0.9f));
+    const float q = IN_RANGE ? exact_div09(t.dist + 0.9f) : 0.9f / (t.dist + 0.9f);
+    const float dist_term = fminf(1.0f, 1.0f - q);
     light = s.light * 2.0f - dist_term;
   }
   const float tt = (1.0f - light) * 32.0f;
@@ -140,8 +148,14 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
       if (id != NONE_ID) {
         const ShadeRec cur = prec[id].s;
         const float py = (float)row + 0.5f, px = (float)(qx * 4u + k) + 0.5f;
-        c = shade_pixel(lv, cmap, cur, px, py, fmaf(cur.wp[1], py, cur.wp[2]), fmaf(cur.up[1], py, cur.up[2]),
-                        fmaf(cur.vp[1], py, cur.vp[2]), width, height, pc);
+        const float row_w = fmaf(cur.wp[1], py, cur.wp[2]), rw = fmaf(cur.wp[0], px, row_w);
+        const bool in_range = ((cur.flags & 3u) == RDOOM_KIND_SKY) | ((rw >= 0x1p-100f) & (rw <= 0x1p100f));
+        if (__all(in_range))  // (wave-uniform choice: one copy of the body runs)
+          c = shade_pixel<true>(lv, cmap, cur, px, py, row_w, fmaf(cur.up[1], py, cur.up[2]), fmaf(cur.vp[1], py, cur.vp[2]),
+                                width, height, pc);
+        else
+          c = shade_pixel<false>(lv, cmap, cur, px, py, row_w, fmaf(cur.up[1], py, cur.up[2]), fmaf(cur.vp[1], py, cur.vp[2]),
+                                 width, height, pc);
         // debug_leak_mod != 0 (tests only): pretend every n-th pixel leaked, so fixup_kernel's general rule
         // is exercised on ordinary pixels too -- the output must not change
         const bool forced = debug_leak_mod != 0u && pix % debug_leak_mod == 0u;
@@ -295,6 +309,11 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
           for (int p = 0; p < NP; p++) rf[p] = rows_of(ww[p]);
         }
         const bool opaque = (any_texel & 0x8000u) == 0u;
+#ifdef RDOOM_FRAG_STATS
+        if (!in_range) atomicAdd(&g_frag_stats[11], 1ull);
+        if (!mod_ok) atomicAdd(&g_frag_stats[12], 1ull);
+        if (!opaque) atomicAdd(&g_frag_stats[13], 1ull);
+#endif
         if (in_range & mod_ok & opaque) {
 #pragma unroll
           for (int p = 0; p < NP; p++) {
@@ -341,6 +360,11 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
       else
         pfb[q0] = out[0];
     }
+#ifdef RDOOM_FRAG_STATS
+    if (valid) atomicAdd(&g_frag_stats[8], 1ull);
+    if (valid && !done) atomicAdd(&g_frag_stats[9], 1ull);
+    if (valid && !uniform) atomicAdd(&g_frag_stats[10], 1ull);
+#endif
     const unsigned long long sm = __ballot(!done);
     if (sm) {  // ordered append of this wave's unfinished quads, then shade full groups of 16
       if (!done) {
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
       uint32_t colour = 0;
       if (best_rec != NONE) {
         const ShadeRec sh = prec[best_rec].s;
-        colour = shade_pixel(lv, lv.colormap, sh, px, py, fmaf(sh.wp[1], py, sh.wp[2]), fmaf(sh.up[1], py, sh.up[2]),
+        colour = shade_pixel<false>(lv, lv.colormap, sh, px, py, fmaf(sh.wp[1], py, sh.wp[2]), fmaf(sh.up[1], py, sh.up[2]),
                              fmaf(sh.vp[1], py, sh.vp[2]), width, height, poses[pose]) & 0xFFu;
       }
       if (vis16)
@@ -503,6 +527,14 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, H, tiles_x, tiles_y,
                      tile_hdr, entries, entry_cap, overflow, fix_count, fix_list, fix_cap, vis, vis16 ? 1u : 0u, prim_out, fb,
                      fix_count + 1);
+#ifdef RDOOM_FRAG_STATS
+  {
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_frag_stats), sizeof h);
+    fprintf(stderr, "[frag stats] runs %llu: to the general body %llu (%.2f %%): mixed %llu, rw out of range %llu, mod uncertified %llu, transparent texel %llu, other (decor, ineligible sizes) %llu\n", h[8], h[9], 100.0 * h[9] / h[8], h[10], h[11], h[12], h[13], h[9] - h[10] - h[11] - h[12] - h[13]);
+  }
+#endif
   return RDOOM_OK;
 }
 

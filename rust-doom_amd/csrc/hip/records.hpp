@@ -17,7 +17,7 @@ namespace rdoom_dev {
 using namespace rdoom_fm;
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr int TILE_W = 64, TILE_H = 64;  // one 256-thread workgroup: 4 waves x 32x32 quadrant, 4x4 pixels per lane
+constexpr int TILE_W = 64, TILE_H = 64;  // one wavefront per tile: four 32x32 quadrants in turn, 4x4 pixels per lane
 
 // ---- level-constant triangle record (built once per level on the host) -----------------------
 struct alignas(16) LevelTri {  // 96 bytes
@@ -160,11 +160,13 @@ struct TexelAt {
   int ix, iy;
   float dist;
 };
+// RCP_EXACT: the caller guarantees 2^-100 <= rw <= 2^100, where fastmath.hpp's exact_rcp equals the division bit for bit.
+template <bool RCP_EXACT = false>
 __device__ __forceinline__ TexelAt texel_coords(const ShadeRec &s, float px, float row_w, float row_u,
                                                 float row_v) {
   TexelAt t;
   const float rw = fmaf(s.wp[0], px, row_w);
-  const float w = 1.0f / rw;
+  const float w = RCP_EXACT ? exact_rcp(rw) : 1.0f / rw;
   const float tu = fmaf(s.up[0], px, row_u) * w;
   const float tv = fmaf(s.vp[0], px, row_v) * w;
   t.dist = w;

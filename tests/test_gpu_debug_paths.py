@@ -6,7 +6,10 @@
   RDOOM_NO_BINS=1         the rasteriser's fallback scan (no per-tile bins), as used when a pose overflows them;
   RDOOM_ENTRY_CAP=n       tile-list entries per pose the binning kernel may emit, to force that overflow;
   RDOOM_FRAG_NQ=1         one quad per lane in the fragment kernel (default two when the width is a multiple of 8);
-  RDOOM_VIS32=1           32-bit visibility words (levels with >= 65535 triangles) instead of 16-bit ones."""
+  RDOOM_VIS32=1           32-bit visibility words (levels with >= 65535 triangles) instead of 16-bit ones;
+  RDOOM_RASTER_DBG=3      the rasteriser without its depth-only body for quadrant-covering triangles (every entry takes
+                          the regular path) -- same image;
+  RDOOM_FRAG_BW=k         the fragment kernel's wave block is 2^k units wide (default 3: 64 x 8 pixels) -- same image."""
 import os
 import re
 import subprocess
@@ -56,6 +59,23 @@ def test_32_bit_visibility_words():
 def test_one_quad_per_lane_fragment_kernel():
     """RDOOM_FRAG_NQ=1: the fragment kernel variant used for frame widths that are not a multiple of 8"""
     bad, _ = run_child({'RDOOM_FRAG_NQ': '1'})
+    assert bad == 0
+
+
+def test_rasteriser_without_the_quadrant_cover_body():
+    bad, _ = run_child({'RDOOM_RASTER_DBG': '3'})
+    assert bad == 0
+    bad, _ = run_child({'RDOOM_RASTER_DBG': '3', 'RDOOM_NO_BINS': '1'})
+    assert bad == 0
+
+
+@pytest.mark.parametrize('bw', ['0', '2', '4', '6'])
+def test_fragment_wave_block_shapes(bw):
+    """1 x 64, 4 x 16, 16 x 4 and 64 x 1 units per wave (frame 320 x 200: 40 units per row, partial blocks in both
+    directions for most shapes)"""
+    bad, _ = run_child({'RDOOM_FRAG_BW': bw})
+    assert bad == 0
+    bad, _ = run_child({'RDOOM_FRAG_BW': bw, 'RDOOM_FRAG_NQ': '1'})
     assert bad == 0
 
 
