@@ -140,8 +140,9 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32+u8', 'data': 'synthetic',
             'frames_per_s': round(args.poses * args.steps * world / elapsed, 1),
-            'config': {'workload': 'E1M1 (synthetic IWAD, tools/mkwad.py) %d-pose sweep at %dx%d per GPU, '
-                                   'walls+flats+decor+sky' % (args.poses, args.width, args.height),
+            'config': {'workload': '%s %d-pose sweep at %dx%d per GPU, walls+flats+decor+sky'
+                                   % ('E1M1 (synthetic IWAD, tools/mkwad.py)' if args.iwad is None and args.level == 0 else
+                                      'level %d of %s' % (args.level, os.path.basename(iwad)), args.poses, args.width, args.height),
                        'poses_per_gpu': args.poses, 'width': args.width, 'height': args.height,
                        'visible_triangles_per_pose': round(vis_tris / args.poses, 1),
                        'alpha_leak_fixup_pixels_per_step': fixups,
