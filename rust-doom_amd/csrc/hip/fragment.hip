@@ -21,8 +21,9 @@ namespace {
 // =================================================================================================
 // Kernel 3: fragment kernel (F1..F6): visibility record -> atlas texel -> COLORMAP row -> 8-bit
 // palette index.  One lane per run of 8 (or 4) horizontally adjacent pixels: one 16-byte visibility
-// load, one 8-byte packed store; COLORMAP (8 KiB) is staged in LDS once per workgroup, which walks
-// FRAG_CHUNK consecutive slabs of one pose (all blocks of a pose run on one XCD).
+// load, one 8-byte packed store; a wavefront takes a block of 8 runs x 8 rows per iteration (64 x 8 pixels: its
+// texel gathers and record loads then fall into a compact patch).  COLORMAP (8 KiB) is staged in LDS once per
+// workgroup, whose four waves walk FRAG_CHUNK such blocks each (all workgroups of a pose run on one XCD).
 //
 // Packed path (96 % of the runs of an E1M1 sweep): the pixels of the run see the same flat/wall triangle
 // whose tile sizes are powers of two or integers.  Its 64-byte shade record is loaded once and the pixels
