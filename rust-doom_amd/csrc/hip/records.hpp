@@ -31,7 +31,7 @@ static_assert(sizeof(LevelTri) == 96, "LevelTri layout");
 
 struct alignas(16) PoseConst {  // 464 bytes
   float pm[16];                 // projection * modelview (V1)
-  float time, vr0, vr1, pad;
+  float time, vr0, vr1, zk;     // zk: depth conditioning constant P[2][2] / P[2][3] (S5)
   uint8_t lights[256];
   float mv[16], proj[16];       // the two uniforms themselves: sprite.vert transforms in two steps (D1..D3)
 };

@@ -363,7 +363,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     pc.time = poses[p].time;
     pc.vr0 = atan2f(pc.pm[8], pc.pm[10]);  // sky.vert:10-12
     pc.vr1 = pc.pm[9] / pc.pm[11];
-    pc.pad = 0;
+    pc.zk = pc.proj[11] != 0.0f ? pc.proj[10] / pc.proj[11] : 0.0f;  // S5: Z - zk * W is small for a perspective matrix
     std::memcpy(pc.lights, lights + (size_t)p * lights_stride, 256);
   }
   b->last_n = n;

@@ -111,10 +111,15 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
         const float det = fmaf(w[0], rr.e[2], fmaf(yw[0], rr.e[1], xw[0] * rr.e[0]));
         ok = det > 0.0f;
         if (ok) {
+          // S5: the depth plane interpolates Z - zk * W (a small residual: the constant P[3][2] for a perspective
+          // matrix) instead of Z, whose dominant part zk * W interpolates to the constant zk exactly; errors of the
+          // edge functions then no longer leak |Z| ~ |W| into window depth
+          const float rz[3] = {fmaf(-pc.zk, clip[0][3], clip[0][2]), fmaf(-pc.zk, clip[1][3], clip[1][2]),
+                               fmaf(-pc.zk, clip[2][3], clip[2][2])};
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             const float e0 = rr.e[c], e1 = rr.e[3 + c], e2 = rr.e[6 + c];
-            const float nz = fmaf(clip[2][2], e2, fmaf(clip[1][2], e1, clip[0][2] * e0));
+            const float nz = fmaf(rz[2], e2, fmaf(rz[1], e1, rz[0] * e0));
             const float n1 = (e0 + e1) + e2;
             const float nu = fmaf(u[2], e2, fmaf(u[1], e1, u[0] * e0));
             const float nv = fmaf(v[2], e2, fmaf(v[1], e1, v[0] * e0));
@@ -123,7 +128,7 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
             sr.up[c] = nu / det;
             sr.vp[c] = nv / det;
           }
-          rr.zp[2] = rr.zp[2] + 0.5f;
+          rr.zp[2] = rr.zp[2] + fmaf(0.5f, pc.zk, 0.5f);
           int x0 = 0, y0 = 0, x1 = width - 1, y1 = height - 1;
           const float wmin = fminf(w[0], fminf(w[1], w[2]));
           wkey = wmin;

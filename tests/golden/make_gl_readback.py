@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/gl_readback/{frames.npz,census.json}: GL readbacks of the REFERENCE's own shaders
+(assets/shaders/*.{vert,frag} of /root/reference, executed by SwiftShader through tests/gl_readback.py) for
+
+  * the 27 golden poses (tests/golden/poses.npy: 9 levels x {spawn view = BASELINE config 2's pose at 320x200, two
+    seeded views, the third at time 1.7 s with its own light table}),
+  * three frames with moving objects (per-object u_modelview, engine/src/renderer.rs:120-132),
+  * pose 0 of the benchmark sweep at 1920x1080 (BASELINE config 3's frame size),
+
+each with the auxiliary winner-id pass, and the mismatch census of the ORACLE's frame against them
+(tests/gl_census.py).  The readbacks are committed so that the GPU box -- which has neither the reference checkout nor
+needs SwiftShader -- can compare the HIP frames with what the reference's shaders produced.
+
+    python tests/golden/make_gl_readback.py          # rewrites the fixtures (needs /root/reference + SwiftShader)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import gl_census  # noqa: E402
+import gl_readback  # noqa: E402
+from oracle import raster, wad_oracle  # noqa: E402
+from util import GOLDEN, META_PATH, ensure_wad  # noqa: E402
+
+OUT = os.path.join(GOLDEN, 'gl_readback')
+
+
+def moving_object_views(lv, modelview, seed):
+    """view o model per object: every dynamic object shifted vertically (tests/test_gpu_raster_parity.py)."""
+    rng = np.random.RandomState(seed)
+    view = np.asarray(modelview, np.float64).reshape(4, 4).T
+    om = np.zeros((int(lv.num_objects), 16), np.float32)
+    for o in range(len(om)):
+        model = np.eye(4)
+        model[1, 3] = 0.0 if o == 0 else rng.uniform(-0.6, 0.6)
+        om[o] = (view @ model).T.astype(np.float32).reshape(16)
+    return om
+
+
+def frame_list():
+    """(key, level index, width, height, pose[33], object seed or None)"""
+    poses = np.load(os.path.join(GOLDEN, 'poses.npy'))
+    out = []
+    for index in range(poses.shape[0]):
+        for i in range(poses.shape[1]):
+            out.append(('L%d_P%d' % (index, i), index, 320, 200, poses[index, i], None))
+    for index, i in ((0, 1), (2, 0), (4, 2)):
+        out.append(('L%d_P%d_objects' % (index, i), index, 320, 200, poses[index, i], 77 + index))
+    return out
+
+
+def bench_pose(width, height):
+    """pose 0 of the benchmark sweep of E1M1 (rust-doom_amd/sharding.py: pose_sweep)"""
+    import importlib
+    import rust_doom_amd as rd
+    sharding = importlib.import_module('rust-doom_amd.sharding')
+    built = rd.Wad(ensure_wad(), META_PATH).build_level(0)
+    p = sharding.pose_sweep(rd, built, 1, width, height)[0]
+    out = np.zeros(33, np.float32)
+    out[:16], out[16:32], out[32] = p['modelview'], p['projection'], p['time']
+    return out
+
+
+def main():
+    wad = ensure_wad()
+    frames = frame_list()
+    frames.append(('L0_bench0_1080p', 0, 1920, 1080, bench_pose(1920, 1080), None))
+    levels, gls, oracles = {}, {}, {}
+    arrays, census = {}, {'swiftshader': gl_readback.gl().version, 'subpixel_bits': gl_readback.gl().subpixel_bits,
+                          'jitter_px': gl_census.JITTER, 'frames': {}}
+    for key, index, w, h, pose, obj_seed in frames:
+        if index not in levels:
+            levels[index] = wad_oracle.build_level(wad, META_PATH, index)
+            gls[index] = gl_readback.GLReference(levels[index])
+            oracles[index] = raster.RasterOracle(levels[index])
+        lv = levels[index]
+        mv, pr, t = pose[:16], pose[16:32], float(pose[32])
+        lights = lv.lights.fill_buffer_at(t)
+        om = None if obj_seed is None else moving_object_views(lv, mv, obj_seed)
+        rgb = gls[index].render(mv, pr, t, lights, w, h, object_modelviews=om)
+        gid = gls[index].render(mv, pr, t, lights, w, h, mode='ids', object_modelviews=om)
+        var = gls[index].render(mv, pr, t, lights, w, h, mode='varyings', object_modelviews=om)
+        fb, prim = oracles[index].render(mv, pr, t, lights, w, h, want_prim=True, object_modelviews=om)
+        c = gl_census.census(lv, mv, pr, t, lights, w, h, fb, prim, rgb, gid, var, object_modelviews=om)
+        c.update(level=index, width=w, height=h, time=t, objects_seed=obj_seed)
+        census['frames'][key] = c
+        arrays[key + '_rgb'] = rgb
+        arrays[key + '_prim'] = gid
+        arrays[key + '_pose'] = np.asarray(pose, np.float32)
+        print(key, {k: v for k, v in c.items() if k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES})
+    tot = {k: sum(f[k] for f in census['frames'].values()) for k in ('pixels', 'mismatch', 'winner_mismatch') + gl_census.CLASSES}
+    census['total'] = tot
+    print('total', tot, 'mismatch fraction %.4f' % (tot['mismatch'] / tot['pixels']))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, 'frames.npz'), **arrays)
+    with open(os.path.join(OUT, 'census.json'), 'w') as f:
+        json.dump(census, f, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()
