@@ -1,24 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- pose-batch throughput of the MI355X renderer (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of synthetic camera poses:
-  H2D of the pose constants -> setup kernel -> tiled rasteriser -> fragment kernel,
-for `--poses` poses (default 1024) at `--width`x`--height` (default 1920x1080) of level E1M1 of the
-synthetic IWAD (no DOOM1.WAD exists here; pass --iwad/--metadata to use a real one).  Level arrays are
-resident in HBM before the timed region; framebuffers stay on the device (D2H is not part of the metric).
+One "step" = one pass of the hot path over one batch of synthetic camera poses per level:
+  H2D of the pose constants -> setup kernel -> binning -> tiled rasteriser -> fragment kernel,
+for `--poses` poses (default 1024) at `--width`x`--height` (default 1920x1080) of level E1M1 of the synthetic IWAD
+(no DOOM1.WAD exists here; pass --iwad/--metadata to use a real one).  Level arrays are resident in HBM before the
+timed region; framebuffers stay on the device (D2H is not part of the metric).
 
-Multi-GPU: one process per GPU (torch.distributed / RCCL used ONLY for the timing barrier and the
-max-over-ranks reduction).  Every rank renders its own disjoint batch of `--poses` poses (weak scaling,
-no data-path collective).
+Workloads (BASELINE.json configs):
+  default                         config 3: E1M1, 1024-pose sweep, 1920x1080, 1 GPU
+  --levels 0-8 [--scaling strong] config 4: E1M1..E1M9, one batch per level, pose ranges [g n/G, (g+1) n/G) per GPU
+  --big --width 3840 --height 2160 --time-varying
+                                  config 5 class: the 10x-E1M1 stand-in for MAP29 at 4K, pose i at time i/35 s with its
+                                  own light table (animated flats, scrolling walls, sector light effects)
 
-Prints ONE JSON line on rank 0 with `roofline` (fragment kernel vs the HBM-read roofline, SURVEY 8(d):
-6 algorithmic bytes read per output pixel) and `cpu_baseline` (the oracle's scalar rasteriser timed on
-the host cores over a bounded sample of the same poses).
+Multi-GPU: one process per GPU, no data-path collective (poses are independent; torch.distributed is used ONLY for the
+timing barrier and the max-over-ranks reduction).  `--gpus N` launched WITHOUT a torch.distributed environment spawns
+the N ranks itself (python -m torch.distributed.run, 127.0.0.1); under torchrun it is one rank of WORLD_SIZE.
+`--scaling weak` (default): every rank renders its own `--poses` poses; `--scaling strong`: ONE batch of `--poses`
+poses is cut into contiguous ranges.  When fewer GPUs are present than ranks (a one-GPU box), ranks wrap onto the GPUs
+present over gloo -- that exercises the code path, it is not a scaling measurement, and the line says so
+(`gpus_present`).
+
+Prints ONE JSON line on rank 0 with `roofline` (fragment kernel vs the HBM-read roofline, SURVEY 8(d): 6 algorithmic
+bytes read per output pixel; plus the actual-bytes fraction from the PMC counters when they were collected for exactly
+this workload and these kernel sources) and `cpu_baseline` (the oracle's scalar rasteriser timed on the host cores over a
+bounded sample of the same poses).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,38 +41,120 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALG_READ_BYTES_PER_PIXEL = 6   # 4 B visibility record + 2 B atlas texel
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--poses', type=int, default=1024)
+    ap.add_argument('--poses', type=int, default=1024, help='poses per GPU (weak) or in total (strong), per level')
     ap.add_argument('--width', type=int, default=1920)
     ap.add_argument('--height', type=int, default=1080)
     ap.add_argument('--level', type=int, default=0)
+    ap.add_argument('--levels', default=None, help='level sweep, e.g. 0-8 or 0,3,5 (BASELINE config 4)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--time-varying', action='store_true', help='pose i at time i/35 s with fill_buffer_at(time) lights')
+    ap.add_argument('--big', action='store_true', help='the 10x-E1M1 synthetic level (stand-in for DOOM2 MAP29)')
     ap.add_argument('--iwad', default=None)
     ap.add_argument('--metadata', default=None)
     ap.add_argument('--cpu-sample', type=int, default=512, help='poses rendered by the CPU oracle (0 = skip)')
-    args = ap.parse_args()
+    ap.add_argument('--dry-run', action='store_true',
+                    help='everything but the device work (rank launch, pose partition, barrier): for hosts without a GPU; prints no value')
+    return ap.parse_args(argv)
+
+
+def level_list(args):
+    if args.levels is None:
+        return [args.level]
+    out = []
+    for part in args.levels.split(','):
+        if '-' in part:
+            lo, hi = part.split('-')
+            out.extend(range(int(lo), int(hi) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def kernel_source_digest():
+    """sha256 over the device sources: PMC traffic figures are only quoted for the kernels they were measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'rust-doom_amd', 'csrc', 'hip')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.hpp')):
+            with open(os.path.join(d, name), 'rb') as f:
+                h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
+def workload_key(args, levels):
+    return '%s|levels=%s|%dx%d|poses=%d|tv=%d' % ('big' if args.big else (os.path.basename(args.iwad) if args.iwad else 'synth'),
+                                                   ','.join(map(str, levels)), args.width, args.height, args.poses,
+                                                   int(args.time_varying))
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torch.distributed environment: launch the N ranks (one process per GPU)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world, rd, sharding, synthetic):
+    """No device work: launches, partitions the sweep exactly as the real run does, meets at the barrier, and reports
+    which pose range every rank would have rendered.  There is no CPU renderer in the product -- no `value`."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+    levels = level_list(args)
+    lo, hi = sharding.shard_range(args.poses, rank, world) if args.scaling == 'strong' else (rank * args.poses, (rank + 1) * args.poses)
+    built = rd.Wad(args.iwad or (synthetic.ensure_big_wad() if args.big else synthetic.ensure_wad()),
+                   args.metadata or synthetic.META_PATH).build_level(levels[0])
+    poses = sharding.pose_sweep(rd, built, hi - lo, args.width, args.height, first=lo)
+    ranges = [None] * world
+    if world > 1:
+        dist.all_gather_object(ranges, (lo, hi, hashlib.sha256(poses.tobytes()).hexdigest()[:16]))
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranges = [(lo, hi, hashlib.sha256(poses.tobytes()).hexdigest()[:16])]
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'value': None, 'n_gpus': world, 'scaling': args.scaling, 'levels': levels,
+                          'pose_ranges': [list(r) for r in ranges]}), flush=True)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
     import rust_doom_amd as rd
-    from util import META_PATH, ensure_wad
     sharding = importlib.import_module('rust-doom_amd.sharding')
+    synthetic = importlib.import_module('rust-doom_amd.synthetic')
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    # one process per GPU; RDOOM_DIST_BACKEND=gloo (with ranks wrapped onto the GPUs present) exists only so that the
-    # N > 1 code path can be exercised on a one-GPU box
-    backend = os.environ.get('RDOOM_DIST_BACKEND', 'nccl')
-    device_index = local_rank if backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
+    if args.dry_run:
+        return dry_run(args, rank, world, rd, sharding, synthetic)
+    present = torch.cuda.device_count()
+    if present < 1:
+        raise SystemExit('bench.py needs a GPU: there is no CPU fallback (--dry-run checks the launch and the partition only)')
+    # one process per GPU over RCCL; with fewer GPUs than ranks the ranks wrap onto the GPUs present and the timing
+    # barrier goes over gloo (RCCL refuses two ranks on one device)
+    backend = os.environ.get('RDOOM_DIST_BACKEND', 'nccl' if present >= world else 'gloo')
+    device_index = local_rank % present
     torch.cuda.set_device(device_index)
     if world > 1:
         import torch.distributed as dist
@@ -70,16 +167,31 @@ def main():
         dist = None
     rd.set_device(device_index)
 
-    iwad = args.iwad or ensure_wad()
-    meta = args.metadata or META_PATH
+    iwad = args.iwad or (synthetic.ensure_big_wad() if args.big else synthetic.ensure_wad())
+    meta = args.metadata or synthetic.META_PATH
     wad = rd.Wad(iwad, meta)
-    t0 = time.perf_counter()
-    built = wad.build_level(args.level, gpu_tessellation=True)   # SSECTOR -> polygon, SEG -> quad kernels
-    t_build = time.perf_counter() - t0
-    level = rd.DeviceLevel(built)                      # level arrays now resident in HBM
-    batch = rd.Batch(level, args.width, args.height, args.poses)
-    poses = sharding.pose_sweep(rd, built, args.poses, args.width, args.height, first=rank * args.poses)
-    lights = built.lights_at(0.0)
+    levels = level_list(args)
+    if args.scaling == 'strong':
+        lo, hi = sharding.shard_range(args.poses, rank, world)   # contiguous ranges of ONE batch
+    else:
+        lo, hi = rank * args.poses, (rank + 1) * args.poses      # every GPU its own batch
+    n_mine = hi - lo
+    work = []
+    t_build = 0.0
+    for index in levels:
+        t0 = time.perf_counter()
+        built = wad.build_level(index, gpu_tessellation=True)   # SSECTOR -> polygon, SEG -> quad kernels
+        t_build += time.perf_counter() - t0
+        level = rd.DeviceLevel(built)                            # level arrays now resident in HBM
+        batch = rd.Batch(level, args.width, args.height, max(n_mine, 1))
+        poses = sharding.pose_sweep(rd, built, n_mine, args.width, args.height, first=lo)
+        if args.time_varying:
+            times = (np.arange(lo, hi) / 35.0).astype(np.float32)
+            poses['time'] = times
+            lights = np.stack([built.lights_at(float(t)) for t in times]) if n_mine else np.zeros((0, 256), np.uint8)
+        else:
+            lights = built.lights_at(0.0)
+        work.append((built, level, batch, poses, lights))
 
     def barrier():
         torch.cuda.synchronize()
@@ -87,74 +199,97 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step(acc=None):
+        for _built, _level, batch, poses, lights in work:
+            if n_mine == 0:
+                continue
+            t = batch.render(poses, lights, timed=True)    # hipEvents on the render stream, per kernel
+            if acc is not None:
+                for k in ('setup_ms', 'raster_ms', 'fragment_ms'):
+                    acc[k] += t[k]
+                acc['visible_triangles'] = acc.get('visible_triangles', 0) + t['visible_triangles']
+                acc['fixup_pixels'] = acc.get('fixup_pixels', 0) + t['fixup_pixels']
+
     for _ in range(args.warmup):
-        batch.render(poses, lights, timed=True)
+        step()
     barrier()
     t_start = time.perf_counter()
-    frag_ms, raster_ms, setup_ms, vis_tris, fixups = [], [], [], 0, 0
+    acc = {'setup_ms': 0.0, 'raster_ms': 0.0, 'fragment_ms': 0.0}
     for _ in range(args.steps):
-        t = batch.render(poses, lights, timed=True)    # hipEvents on the render stream, per kernel
-        frag_ms.append(t['fragment_ms'])
-        raster_ms.append(t['raster_ms'])
-        setup_ms.append(t['setup_ms'])
-        vis_tris = t['visible_triangles']
-        fixups = t['fixup_pixels']
+        step(acc)
     barrier()
     elapsed = time.perf_counter() - t_start
     elapsed = sharding.max_over_ranks(elapsed, dist, 'cuda' if backend == 'nccl' else 'cpu')
 
     if rank == 0:
-        px_per_step = args.poses * args.width * args.height
-        total_px = px_per_step * args.steps * world
-        frag = float(np.mean(frag_ms))
-        achieved = px_per_step * ALG_READ_BYTES_PER_PIXEL / (frag * 1e-3) / 1e9
-        traffic = None
+        frame_px = args.width * args.height
+        poses_per_step_global = (args.poses if args.scaling == 'strong' else args.poses * world) * len(levels)
+        total_px = poses_per_step_global * frame_px * args.steps
+        my_px_per_step = n_mine * frame_px * len(levels)
+        frag = acc['fragment_ms'] / args.steps             # this rank's fragment-kernel time per step (all levels)
+        achieved = my_px_per_step * ALG_READ_BYTES_PER_PIXEL / (frag * 1e-3) / 1e9 if frag > 0 else 0.0
+        traffic = frac_actual = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_fragment_latest.json')
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world == 1:
             try:
-                rec = json.load(open(pmc))  # PMC passes of an earlier profile run (tools/profile_round.sh) on this workload
-                if (rec.get('poses'), rec.get('width'), rec.get('height')) == (args.poses, args.width, args.height):
+                rec = json.load(open(pmc))  # PMC passes of an earlier profile run (tools/profile_round.sh)
+                if rec.get('workload') == workload_key(args, levels) and rec.get('kernel_sources') == kernel_source_digest():
                     traffic = rec.get('hbm_bytes_per_launch')
+                    frac_actual = round(traffic / (frag * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             except Exception:
                 traffic = None
         cpu = None
         if args.cpu_sample > 0 and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             from oracle import raster
+            built, _level, _batch, poses, lights = work[0]
             ro = raster.RasterOracle(built.arrays())
             cores = os.cpu_count() or 1
-            n = min(args.cpu_sample, args.poses)
+            n = min(args.cpu_sample, n_mine)
             sample = np.zeros((n, 33), np.float32)
             sample[:, :16] = poses['modelview'][:n]
             sample[:, 16:32] = poses['projection'][:n]
             sample[:, 32] = poses['time'][:n]
+            li = lights[:n] if lights.ndim == 2 else np.tile(lights, (n, 1))
             tc = time.perf_counter()
-            ro.render_batch(sample, np.tile(lights, (n, 1)), args.width, args.height, threads=cores)
+            ro.render_batch(sample, li, args.width, args.height, threads=cores)
             tc = time.perf_counter() - tc
-            cpu = {'value': round(n * args.width * args.height / tc / 1e6, 3), 'unit': 'Mpixels/s',
+            cpu = {'value': round(n * frame_px / tc / 1e6, 3), 'unit': 'Mpixels/s',
                    'cores': min(cores, n), 'kind': 'port',
                    'sample': '%d poses of the same sweep at %dx%d, oracle/raster_oracle.c, %.1f s; level build '
                              '(C++ walk + device tessellation kernels, first use) %.1f ms' % (n, args.width, args.height, tc, t_build * 1e3)}
+        if args.iwad:
+            what = 'level(s) %s of %s' % (','.join(map(str, levels)), os.path.basename(iwad))
+        elif args.big:
+            what = '10x-E1M1 synthetic level (MAP29 stand-in, tools/mkwad.py)'
+        elif levels == [0]:
+            what = 'E1M1 (synthetic IWAD, tools/mkwad.py)'
+        else:
+            what = 'E1M%s (synthetic IWAD, tools/mkwad.py), one batch per level' % ','.join(str(i + 1) for i in levels)
         out = {
             'metric': 'Mpixels/s, E1M1 1920x1080 pose batch', 'value': round(total_px / elapsed / 1e6, 1),
             'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f32+u8', 'data': 'synthetic',
-            'frames_per_s': round(args.poses * args.steps * world / elapsed, 1),
-            'config': {'workload': '%s %d-pose sweep at %dx%d per GPU, walls+flats+decor+sky'
-                                   % ('E1M1 (synthetic IWAD, tools/mkwad.py)' if args.iwad is None and args.level == 0 else
-                                      'level %d of %s' % (args.level, os.path.basename(iwad)), args.poses, args.width, args.height),
-                       'poses_per_gpu': args.poses, 'width': args.width, 'height': args.height,
-                       'visible_triangles_per_pose': round(vis_tris / args.poses, 1),
-                       'alpha_leak_fixup_pixels_per_step': fixups,
-                       'kernels_ms': {'setup': round(float(np.mean(setup_ms)), 3),
-                                      'raster': round(float(np.mean(raster_ms)), 3), 'fragment': round(frag, 3)},
-                       'parallelism': 'pose-sharded x%d, no collective' % world},
+            'frames_per_s': round(poses_per_step_global * args.steps / elapsed, 1),
+            'config': {'workload': '%s %d-pose sweep at %dx%d %s, walls+flats+decor+sky%s'
+                                   % (what, args.poses, args.width, args.height,
+                                      'per GPU' if args.scaling == 'weak' else 'in total, cut into contiguous ranges',
+                                      ', pose i at time i/35 s with its own light table' if args.time_varying else ''),
+                       'levels': levels, 'poses_per_gpu': n_mine, 'width': args.width, 'height': args.height,
+                       'visible_triangles_per_pose': round(acc.get('visible_triangles', 0) / max(1, args.steps * n_mine * len(levels)), 1),
+                       'alpha_leak_fixup_pixels_per_step': acc.get('fixup_pixels', 0) // max(1, args.steps),
+                       'kernels_ms': {k[:-3]: round(acc[k] / args.steps, 3) for k in ('setup_ms', 'raster_ms', 'fragment_ms')},
+                       'parallelism': 'pose-sharded x%d, no collective' % world,
+                       'workload_key': workload_key(args, levels), 'kernel_sources': kernel_source_digest()},
             'roofline': {'bound': 'hbm', 'kernel': 'fragment_kernel', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': traffic},
+                         'traffic': traffic, 'frac_actual_bytes': frac_actual},
             'cpu_baseline': cpu,
         }
-        print(json.dumps(out))
+        if present < world:
+            out['gpus_present'] = present
+            out['note'] = '%d ranks wrapped onto %d GPU(s) over gloo: exercises the N > 1 path, not a scaling measurement' % (world, present)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

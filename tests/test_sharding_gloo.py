@@ -77,3 +77,25 @@ def test_sweep_is_deterministic_and_slices_compose():
     b = sharding.pose_sweep(rd, built, 8, W, H, first=8)
     assert a[8:].tobytes() == b.tobytes()
     assert sharding.max_over_ranks(3.5) == 3.5
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed environment launches two ranks itself (the way the driver
+    calls it); --dry-run stops short of the device work so this runs on a host without a GPU."""
+    import json
+    import subprocess
+    import sys
+    from util import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    for scaling, want in (('strong', [[0, 12], [12, 24]]), ('weak', [[0, 24], [24, 48]])):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--poses', '24',
+                              '--width', '64', '--height', '40', '--scaling', scaling],
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+        assert line['n_gpus'] == 2 and line['scaling'] == scaling
+        assert [r[:2] for r in line['pose_ranges']] == want
+        built = rd.Wad(ensure_wad(), META_PATH).build_level(0)
+        for lo, hi, digest in line['pose_ranges']:
+            full = sharding.pose_sweep(rd, built, hi - lo, 64, 40, first=lo)
+            assert hashlib.sha256(full.tobytes()).hexdigest()[:16] == digest

@@ -10,47 +10,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-GOLDEN = os.path.join(ROOT, 'tests', 'golden')
-WAD_PATH = os.path.join(GOLDEN, 'synth.wad')
-META_PATH = os.path.join(ROOT, 'assets', 'meta', 'synth.toml')
+import importlib  # noqa: E402
+
+_syn = importlib.import_module('rust-doom_amd.synthetic')
+GOLDEN, WAD_PATH, BIG_WAD_PATH, META_PATH = _syn.GOLDEN, _syn.WAD_PATH, _syn.BIG_WAD_PATH, _syn.META_PATH
+ensure_wad, ensure_big_wad, wad_digest = _syn.ensure_wad, _syn.ensure_big_wad, _syn.wad_digest
 F = np.float32
-
-
-def ensure_wad():
-    """The synthetic IWAD is generated (seeded, deterministic), not committed; its digest is."""
-    if not os.path.exists(WAD_PATH):
-        sys.path.insert(0, os.path.join(ROOT, 'tools'))
-        import mkwad
-        wad, _ = mkwad.build_wad(1993)
-        os.makedirs(GOLDEN, exist_ok=True)
-        tmp = '%s.%d.tmp' % (WAD_PATH, os.getpid())  # several ranks may get here at once: write aside, then rename
-        with open(tmp, 'wb') as f:
-            f.write(wad)
-        os.replace(tmp, WAD_PATH)
-    return WAD_PATH
-
-
-BIG_WAD_PATH = os.path.join(GOLDEN, 'synth_big.wad')
-
-
-def ensure_big_wad():
-    """A second synthetic IWAD with ONE level ten times the size of E1M1 (7.2 k linedefs, 3 k sub-sectors, ~36 k
-    triangles: larger than any level of DOOM / DOOM2), generated on demand like the first."""
-    if not os.path.exists(BIG_WAD_PATH):
-        sys.path.insert(0, os.path.join(ROOT, 'tools'))
-        import mkwad
-        wad, _ = mkwad.build_wad(1993, specs=[('E1M1', ('gen', 424242, 128, 90))])
-        os.makedirs(GOLDEN, exist_ok=True)
-        tmp = '%s.%d.tmp' % (BIG_WAD_PATH, os.getpid())
-        with open(tmp, 'wb') as f:
-            f.write(wad)
-        os.replace(tmp, BIG_WAD_PATH)
-    return BIG_WAD_PATH
-
-
-def wad_digest():
-    with open(ensure_wad(), 'rb') as f:
-        return hashlib.sha256(f.read()).hexdigest()
 
 
 def perspective(fovy_deg, aspect, near, far):

@@ -36,7 +36,9 @@ fetch = sum(vals['FETCH_SIZE']) / len(vals['FETCH_SIZE'])
 write = sum(vals['WRITE_SIZE']) / len(vals['WRITE_SIZE'])
 bench = json.loads(line)
 out = {'kernel': 'fragment_kernel', 'poses': bench['config']['poses_per_gpu'], 'width': bench['config']['width'],
-       'height': bench['config']['height'], 'FETCH_SIZE_KiB': fetch, 'WRITE_SIZE_KiB': write,
+       'height': bench['config']['height'], 'workload': bench['config']['workload_key'],
+       'kernel_sources': bench['config']['kernel_sources'],  # bench.py quotes the traffic only for this workload AND these device sources
+       'FETCH_SIZE_KiB': fetch, 'WRITE_SIZE_KiB': write,
        'hbm_read_bytes_per_launch': 2.0 * fetch * 1024.0, 'hbm_write_bytes_per_launch': write * 1024.0,
        'hbm_bytes_per_launch': 2.0 * fetch * 1024.0 + write * 1024.0,
        'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950, 16 B/lane reads)',
