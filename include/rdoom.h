@@ -188,6 +188,13 @@ rdoom_status rdoom_batch_read_primitive_ids(rdoom_batch *batch, uint32_t first, 
  * [7] packed-vs-scalar mismatches.  [0], [1], [3], [7] must be 0. */
 rdoom_status rdoom_selftest_fastmath(uint64_t out_counts[8]);
 
+/* Test hooks (no reference counterpart; the library never reads the environment).  Each option selects a differently
+ * shaped but EQUIVALENT path through the kernels -- the image must not change -- so that the rarely taken ones can be
+ * forced (tests/test_gpu_debug_paths.py).  Process-wide; read when a batch is created ("vis32", "entry_cap") or
+ * rendered (the rest).  Names: no_bins, entry_cap, vis32, leak_mod, frag_nq, frag_bw, frag_chunk, bin_threads,
+ * defer_all, defer_cap, no_cover, raster_stats (rust-doom_amd/csrc/common.hpp: DebugOptions); "reset" restores the defaults. */
+rdoom_status rdoom_debug_set(const char *name, int32_t value);
+
 /* ---- loader + builder: the `wad` crate and `game::level` static-geometry builder ----------- */
 /* Archive::open (wad/src/archive.rs:36-60) + TextureDirectory::from_archive (wad/src/tex.rs:53-107) */
 rdoom_status rdoom_wad_open(const char *wad_path, const char *metadata_path, rdoom_wad **out_wad);

@@ -76,7 +76,7 @@ API_SYMBOLS = [
     'rdoom_wad_open', 'rdoom_wad_close', 'rdoom_wad_num_levels', 'rdoom_wad_level_name',
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
     'rdoom_built_counters', 'rdoom_built_lights_at', 'rdoom_built_start', 'rdoom_built_floor_centroids',
-    'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_batch_render_objects', 'rdoom_level_num_objects', 'rdoom_batch_enable_primitive_ids']
+    'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_debug_set', 'rdoom_batch_render_objects', 'rdoom_level_num_objects', 'rdoom_batch_enable_primitive_ids']
 
 _lib = None
 
@@ -118,6 +118,11 @@ def device_count():
 
 def set_device(i):
     _check(lib().rdoom_set_device(int(i)))
+
+
+def debug_set(name, value=1):
+    """rdoom_debug_set: test hooks selecting equivalent kernel paths (include/rdoom.h); 'reset' restores the defaults."""
+    _check(lib().rdoom_debug_set(name.encode('ascii'), int(value)))
 
 
 def selftest_fastmath():

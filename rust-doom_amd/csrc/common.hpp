@@ -8,6 +8,24 @@
 
 namespace rdoom {
 std::string &last_error_ref();
+
+// Test hooks set through rdoom_debug_set (include/rdoom.h): every one of them selects a differently shaped but
+// EQUIVALENT path -- the image must not change (tests/test_gpu_debug_paths.py).  Nothing reads the environment.
+struct DebugOptions {
+  int no_bins = 0;       // rasterise from the sorted list (the fallback used when a pose overflows its tile lists)
+  int entry_cap = 0;     // tile-list entries per pose (0 = default), to force that overflow
+  int vis32 = 0;         // 32-bit visibility words (the format of levels with >= 65535 triangles)
+  int leak_mod = 0;      // every n-th pixel is queued as an alpha leak: fixup_kernel re-resolves ordinary pixels
+  int frag_nq = 2;       // quads per lane in the fragment kernel (1 = the variant for widths that are not a multiple of 8)
+  int frag_bw = 3;       // log2(units per row of the fragment kernel's wave block)
+  int frag_chunk = 0;    // wave blocks per wave in the fragment kernel (0 = default)
+  int bin_threads = 256; // workgroup size of the binning kernel
+  int defer_all = 0;     // the rasteriser defers every entry: the repair kernel resolves the whole frame
+  int defer_cap = 0;     // deferred pairs a tile may list (0 = default 64), to force the replay of whole tile lists
+  int no_cover = 0;      // no depth-only body for quadrant-covering triangles
+  int raster_stats = 0;  // census of the rasteriser's paths on stderr (instrumented instantiation: slower)
+};
+DebugOptions &debug_options();
 inline rdoom_status fail(rdoom_status code, const char *fmt, ...) {
   char buf[512];
   va_list ap;

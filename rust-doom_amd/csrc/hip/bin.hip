@@ -161,15 +161,22 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restri
 
 }  // namespace
 
-void launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
+bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
                 uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
                 uint32_t *overflow) {
   const uint32_t bin_tiles = std::min<uint32_t>((uint32_t)(tiles_x * tiles_y), MAX_TILES);
-  static const int bin_threads = getenv("RDOOM_BIN_THREADS") ? atoi(getenv("RDOOM_BIN_THREADS")) : 256;  // tuning switch
+  const int bin_threads = rdoom::debug_options().bin_threads;
   auto bk = bin_threads == 512 ? bin_kernel<512, 9> : (bin_threads == 128 ? bin_kernel<128, 7> : bin_kernel<256, 8>);
   const int bt = bin_threads == 512 ? 512 : (bin_threads == 128 ? 128 : 256);
+  // LDS budget: the kernel's static arrays plus two counters per tile must fit the 64 KiB a workgroup may use; frames
+  // with more tiles than that (beyond ~5 900: 7680x4320 and up) are rasterised from the sorted list instead
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(bk)) != hipSuccess ||
+      attr.sharedSizeBytes + 2 * sizeof(uint32_t) * bin_tiles > 65536u || (uint32_t)(tiles_x * tiles_y) > MAX_TILES)
+    return false;
   hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bt), 2 * sizeof(uint32_t) * bin_tiles, st, recs, sorted, counts, cap, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow);
+  return true;
 }
 
 }  // namespace rdoom_dev

@@ -506,23 +506,24 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
         (hi < qpp && (uint32_t)(((uint64_t)hi * div_m) >> 32) >> div_sh != k))
       return rdoom::fail(RDOOM_BAD_ARG, "internal: fast_div constants invalid for width %d", W);
   }
-  static const uint32_t debug_leak_mod = getenv("RDOOM_DEBUG_LEAK_MOD") ? (uint32_t)atoi(getenv("RDOOM_DEBUG_LEAK_MOD")) : 0u;
-  static const int frag_nq_env = getenv("RDOOM_FRAG_NQ") ? atoi(getenv("RDOOM_FRAG_NQ")) : 2;  // tuning switch / tests
-  static const int frag_dbg = getenv("RDOOM_FRAG_DBG") ? atoi(getenv("RDOOM_FRAG_DBG")) : 0;  // timing experiments (wrong images)
-  const int nq = (frag_nq_env == 2 && W % 8 == 0) ? 2 : 1;  // quads per lane: two when rows divide into 8-pixel runs
-  static const uint32_t bwl = getenv("RDOOM_FRAG_BW") ? (uint32_t)std::min(6, std::max(0, atoi(getenv("RDOOM_FRAG_BW")))) : 3u;  // tuning switch: log2(units per block row)
+  const rdoom::DebugOptions &dbg = rdoom::debug_options();  // test hooks: equivalent paths, same image
+  const uint32_t debug_leak_mod = (uint32_t)std::max(0, dbg.leak_mod);
+  const int nq = (dbg.frag_nq == 2 && W % 8 == 0) ? 2 : 1;  // quads per lane: two when rows divide into 8-pixel runs
+  const uint32_t bwl = (uint32_t)std::min(6, std::max(0, dbg.frag_bw));  // log2(units per block row)
   const uint32_t bw = 1u << bwl, bh = 64u >> bwl;
   const uint32_t wbpr = (qpr / (uint32_t)nq + bw - 1u) / bw, wbpp = wbpr * (((uint32_t)H + bh - 1u) / bh);  // bw-unit x bh-row blocks
-  static const uint32_t frag_chunk =
-      getenv("RDOOM_FRAG_CHUNK") ? (uint32_t)std::max(1, atoi(getenv("RDOOM_FRAG_CHUNK"))) : (uint32_t)FRAG_CHUNK;  // tuning switch
+  const uint32_t frag_chunk = dbg.frag_chunk > 0 ? (uint32_t)dbg.frag_chunk : (uint32_t)FRAG_CHUNK;
   const uint32_t fblocks = (wbpp + frag_chunk * 4u - 1u) / (frag_chunk * 4u);  // a workgroup = 4 waves x frag_chunk blocks
   HIP_TRY(hipMemsetAsync(fix_count, 0, 2 * sizeof(uint32_t), st));
   const uint64_t fgrid = (uint64_t)((n + 7) / 8) * 8ull * fblocks;
   if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
   auto frag = nq == 2 ? (vis16 ? fragment_kernel<2, 0, true> : fragment_kernel<2, 0, false>)
                       : (vis16 ? fragment_kernel<1, 0, true> : fragment_kernel<1, 0, false>);
-  if (frag_dbg == 2) frag = nq == 2 ? (vis16 ? fragment_kernel<2, 2, true> : fragment_kernel<2, 2, false>)
-                               : (vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>);
+#ifdef RDOOM_TIMING_EXPERIMENTS  // wrong images by design: never in the shipped library
+  if (getenv("RDOOM_FRAG_DBG") && atoi(getenv("RDOOM_FRAG_DBG")) == 2)
+    frag = nq == 2 ? (vis16 ? fragment_kernel<2, 2, true> : fragment_kernel<2, 2, false>)
+                   : (vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>);
+#endif
   hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp,
                      qpr, div_m, div_sh, wbpr, wbpp, bwl, W, H, ndc_tab, fb, fix_count, fix_list, fix_cap, debug_leak_mod);
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, H, tiles_x, tiles_y,

@@ -42,6 +42,8 @@ struct rdoom_batch {
   uint32_t *d_entries = nullptr;   // per pose: entry_cap tile-list entries (record index | quadrant mask << 28)
   uint32_t *d_overflow = nullptr;  // per pose: 1 = bins incomplete, rasteriser scans the sorted list
   uint32_t entry_cap = 0, n_tiles = 0;
+  uint32_t *d_repair_count = nullptr;  // tiles that deferred entries to the rasteriser's repair kernel
+  void *d_repair_store = nullptr;      // their items and (quadrant, record) pair lists
   uint32_t *d_fix_count = nullptr;  // [0] = queued pixels, [1] = error flag (fixup list overflow)
   uint2 *d_fix_list = nullptr;
   uint32_t fix_cap = 1u << 20;
@@ -260,7 +262,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
 void rdoom_batch_destroy(rdoom_batch *b) {
   if (!b) return;
   for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_tmp_recs, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries,
-                  (void *)b->d_overflow, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
+                  (void *)b->d_overflow, (void *)b->d_repair_count, b->d_repair_store, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb})
     if (p) (void)hipFree(p);
   for (auto &e : b->ev)
@@ -286,7 +288,8 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   b->height = height;
   b->max_poses = max_poses;
   b->cap = level->ntri ? level->ntri : 1;
-  b->vis16 = b->cap < 0xFFFFu && getenv("RDOOM_VIS32") == nullptr;  // RDOOM_VIS32: tests force the 32-bit words
+  const rdoom::DebugOptions &dbg = rdoom::debug_options();
+  b->vis16 = b->cap < 0xFFFFu && !dbg.vis32;
   const size_t npx = (size_t)width * height * max_poses;
   hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
@@ -294,10 +297,12 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_sorted, sizeof(uint4) * (size_t)b->cap * max_poses);
   b->n_tiles = ((width + TILE_W - 1) / TILE_W) * ((height + TILE_H - 1) / TILE_H);
   b->entry_cap = std::max<uint32_t>(65536u, 32u * b->n_tiles);  // tile-list entries per pose; beyond it the pose is scanned
-  if (const char *dbg = getenv("RDOOM_ENTRY_CAP")) b->entry_cap = (uint32_t)std::max(1, atoi(dbg));  // tests: force that fallback
+  if (dbg.entry_cap > 0) b->entry_cap = (uint32_t)dbg.entry_cap;  // tests: force that fallback
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_tile_hdr, sizeof(uint2) * (size_t)b->n_tiles * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_entries, sizeof(uint32_t) * (size_t)b->entry_cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_overflow, sizeof(uint32_t) * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_repair_count, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&b->d_repair_store, raster_repair_bytes(max_poses, b->n_tiles));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_count, 2 * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_list, sizeof(uint2) * (size_t)b->fix_cap);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
@@ -378,18 +383,17 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     launch_setup(st, n, lv->view, b->d_poses, object_modelviews ? (const ObjectConst *)b->d_objects : nullptr, lv->n_objects,
                  W, H, kinds_mask, b->d_recs, b->d_tmp_recs, b->d_sorted, b->d_counts, b->cap);
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
-  static const bool no_bins = getenv("RDOOM_NO_BINS") != nullptr;  // debug: exercise the fallback scan
-  if (lv->ntri && !no_bins) {
-    launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap,
-               b->d_overflow);
-  } else {
+  if (!(lv->ntri && !rdoom::debug_options().no_bins &&
+        launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
+                   b->entry_cap, b->d_overflow))) {
     HIP_TRY(hipMemsetAsync(b->d_overflow, 0xFF, sizeof(uint32_t) * n, st));
     if (!lv->ntri) HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
   }
   if (tm) HIP_TRY(hipEventRecord(b->ev[1], st));
   uint32_t *prim_out = b->want_prim ? b->d_prim : nullptr;
   if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, W, H, tiles_x, tiles_y,
-                                      b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out))
+                                      b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out,
+                                      b->d_repair_count, b->d_repair_store, b->max_poses))
     return rs;
   if (tm) HIP_TRY(hipEventRecord(b->ev[2], st));
   if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, b->d_poses, W, H, tiles_x,

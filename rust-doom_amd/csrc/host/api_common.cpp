@@ -9,9 +9,35 @@ std::string &last_error_ref() {
   static thread_local std::string err;
   return err;
 }
+DebugOptions &debug_options() {
+  static DebugOptions opts;
+  return opts;
+}
 }  // namespace rdoom
 
 extern "C" {
+
+rdoom_status rdoom_debug_set(const char *name, int32_t value) {
+  if (!name) return rdoom::fail(RDOOM_BAD_ARG, "name is null");
+  rdoom::DebugOptions &o = rdoom::debug_options();
+  const struct {
+    const char *name;
+    int *field;
+  } table[] = {{"no_bins", &o.no_bins},     {"entry_cap", &o.entry_cap},   {"vis32", &o.vis32},
+               {"leak_mod", &o.leak_mod},   {"frag_nq", &o.frag_nq},       {"frag_bw", &o.frag_bw},
+               {"frag_chunk", &o.frag_chunk}, {"bin_threads", &o.bin_threads}, {"defer_all", &o.defer_all},
+               {"defer_cap", &o.defer_cap}, {"no_cover", &o.no_cover},     {"raster_stats", &o.raster_stats}};
+  for (const auto &t : table)
+    if (std::strcmp(t.name, name) == 0) {
+      *t.field = value;
+      return RDOOM_OK;
+    }
+  if (std::strcmp(name, "reset") == 0) {
+    o = rdoom::DebugOptions{};
+    return RDOOM_OK;
+  }
+  return rdoom::fail(RDOOM_BAD_ARG, "unknown debug option '%s'", name);
+}
 
 const char *rdoom_last_error(void) { return rdoom::last_error_ref().c_str(); }
 

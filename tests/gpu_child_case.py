@@ -1,5 +1,5 @@
-"""Child process of tests/test_gpu_debug_paths.py: renders a small sweep through the C ABI with whatever
-RDOOM_* debug environment the parent set (they are read once per process) and checks it against the oracle."""
+"""Child process of tests/test_gpu_debug_paths.py: renders a small sweep through the C ABI with the test hooks
+(rdoom_debug_set: name=value arguments after the four numbers) the parent asked for and checks it against the oracle."""
 import sys
 
 import numpy as np
@@ -13,6 +13,9 @@ from util import META_PATH, ensure_wad
 
 def main():
     index, w, h, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    for setting in sys.argv[5:]:
+        name, value = setting.split('=')
+        rd.debug_set(name, int(value))
     lv = wad_oracle.build_level(ensure_wad(), META_PATH, index)
     poses = sweep_poses(lv, n, w, h, seed=11, time=0.4)
     lights = lv.lights.fill_buffer_at(0.4)

@@ -1,15 +1,15 @@
-"""GPU: the rarely taken paths, forced through environment switches the library reads once per process
-(hence child processes):
-  RDOOM_DEBUG_LEAK_MOD=n  every n-th pixel is treated as an alpha leak, so fixup_kernel's general per-pixel
-                          rule (all candidates of the tile, lexicographic (depth, primitive) minimum) re-resolves
-                          ordinary pixels -- output must be unchanged;
-  RDOOM_NO_BINS=1         the rasteriser's fallback scan (no per-tile bins), as used when a pose overflows them;
-  RDOOM_ENTRY_CAP=n       tile-list entries per pose the binning kernel may emit, to force that overflow;
-  RDOOM_FRAG_NQ=1         one quad per lane in the fragment kernel (default two when the width is a multiple of 8);
-  RDOOM_VIS32=1           32-bit visibility words (levels with >= 65535 triangles) instead of 16-bit ones;
-  RDOOM_RASTER_DBG=3      the rasteriser without its depth-only body for quadrant-covering triangles (every entry takes
-                          the regular path) -- same image;
-  RDOOM_FRAG_BW=k         the fragment kernel's wave block is 2^k units wide (default 3: 64 x 8 pixels) -- same image."""
+"""GPU: the rarely taken paths, forced through the library's test hooks (rdoom_debug_set, include/rdoom.h; each child
+process sets its own, they are process-wide).  Every hook selects an equivalent path: the image must not change.
+  leak_mod=n     every n-th pixel is treated as an alpha leak, so fixup_kernel's general per-pixel rule (all candidates of
+                 the tile, lexicographic (depth, primitive) minimum) re-resolves ordinary pixels;
+  no_bins=1      the rasteriser's fallback scan (no per-tile bins), as used when a pose overflows them;
+  entry_cap=n    tile-list entries per pose the binning kernel may emit, to force that overflow;
+  frag_nq=1      one quad per lane in the fragment kernel (default two when the width is a multiple of 8);
+  vis32=1        32-bit visibility words (levels with >= 65535 triangles) instead of 16-bit ones;
+  no_cover=1     the rasteriser without its depth-only body for quadrant-covering triangles;
+  defer_all=1    the rasteriser defers every entry: raster_repair_kernel resolves the whole frame with the general body;
+  defer_cap=n    deferred pairs a tile may list before its whole list is replayed by the repair kernel;
+  frag_bw=k      the fragment kernel's wave block is 2^k units wide (default 3: 64 x 8 pixels)."""
 import os
 import re
 import subprocess
@@ -21,61 +21,79 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_child(env_extra, args=('0', '320', '200', '6')):
-    env = dict(os.environ, **env_extra)
-    p = subprocess.run([sys.executable, os.path.join(HERE, 'gpu_child_case.py'), *args], env=env, cwd=HERE,
-                       capture_output=True, text=True, timeout=600)
+def run_child(hooks, args=('0', '320', '200', '6')):
+    p = subprocess.run([sys.executable, os.path.join(HERE, 'gpu_child_case.py'), *args, *['%s=%s' % kv for kv in hooks.items()]],
+                       cwd=HERE, capture_output=True, text=True, timeout=600)
     m = re.search(r'RESULT bad=(\d+) fixups=(\d+)', p.stdout)
     assert m, p.stdout + p.stderr
     return int(m.group(1)), int(m.group(2))
 
 
 def test_forced_alpha_leak_fixups_do_not_change_the_image():
-    bad, fixups = run_child({'RDOOM_DEBUG_LEAK_MOD': '97'})
+    bad, fixups = run_child({'leak_mod': 97})
     assert bad == 0
     assert fixups > 3000  # about 1/97 of 6 x 320 x 200 covered pixels went through fixup_kernel
 
 
 def test_fallback_scan_without_bins():
-    bad, _ = run_child({'RDOOM_NO_BINS': '1'})
+    bad, _ = run_child({'no_bins': 1})
     assert bad == 0
 
 
 def test_tile_list_overflow_falls_back_to_the_scan():
-    """RDOOM_ENTRY_CAP=300: nearly every pose needs more tile-list entries than that, sets its overflow flag and is rasterised by the scan"""
-    bad, _ = run_child({'RDOOM_ENTRY_CAP': '300'})
+    """entry_cap=300: nearly every pose needs more tile-list entries than that, sets its overflow flag and is rasterised by the scan"""
+    bad, _ = run_child({'entry_cap': 300})
     assert bad == 0
 
 
 def test_32_bit_visibility_words():
-    """RDOOM_VIS32=1: the visibility buffer keeps 32-bit record indices (the format used when a level has 65535 or
+    """vis32=1: the visibility buffer keeps 32-bit record indices (the format used when a level has 65535 or
     more triangles) instead of the 16-bit words the synthetic levels qualify for"""
-    bad, _ = run_child({'RDOOM_VIS32': '1'})
+    bad, _ = run_child({'vis32': 1})
     assert bad == 0
-    bad, fixups = run_child({'RDOOM_VIS32': '1', 'RDOOM_DEBUG_LEAK_MOD': '101'})
+    bad, fixups = run_child({'vis32': 1, 'leak_mod': 101})
     assert bad == 0 and fixups > 3000
+    bad, _ = run_child({'vis32': 1, 'defer_all': 1})
+    assert bad == 0
 
 
 def test_one_quad_per_lane_fragment_kernel():
-    """RDOOM_FRAG_NQ=1: the fragment kernel variant used for frame widths that are not a multiple of 8"""
-    bad, _ = run_child({'RDOOM_FRAG_NQ': '1'})
+    """frag_nq=1: the fragment kernel variant used for frame widths that are not a multiple of 8"""
+    bad, _ = run_child({'frag_nq': 1})
     assert bad == 0
 
 
 def test_rasteriser_without_the_quadrant_cover_body():
-    bad, _ = run_child({'RDOOM_RASTER_DBG': '3'})
+    bad, _ = run_child({'no_cover': 1})
     assert bad == 0
-    bad, _ = run_child({'RDOOM_RASTER_DBG': '3', 'RDOOM_NO_BINS': '1'})
+    bad, _ = run_child({'no_cover': 1, 'no_bins': 1})
     assert bad == 0
 
 
-@pytest.mark.parametrize('bw', ['0', '2', '4', '6'])
+def test_repair_kernel_resolves_everything_when_all_entries_are_deferred():
+    """defer_all=1: the hot rasteriser applies nothing; every (quadrant, record) pair goes through raster_repair_kernel's
+    general body -- tiles with more than 64 pairs through the whole-list replay"""
+    bad, _ = run_child({'defer_all': 1})
+    assert bad == 0
+    bad, _ = run_child({'defer_all': 1, 'no_bins': 1})
+    assert bad == 0
+
+
+@pytest.mark.parametrize('cap', [1, 3])
+def test_deferred_pair_list_overflow_replays_the_tile_list(cap):
+    bad, _ = run_child({'defer_cap': cap})
+    assert bad == 0
+    bad, _ = run_child({'defer_cap': cap, 'entry_cap': 300})
+    assert bad == 0
+
+
+@pytest.mark.parametrize('bw', [0, 2, 4, 6])
 def test_fragment_wave_block_shapes(bw):
     """1 x 64, 4 x 16, 16 x 4 and 64 x 1 units per wave (frame 320 x 200: 40 units per row, partial blocks in both
     directions for most shapes)"""
-    bad, _ = run_child({'RDOOM_FRAG_BW': bw})
+    bad, _ = run_child({'frag_bw': bw})
     assert bad == 0
-    bad, _ = run_child({'RDOOM_FRAG_BW': bw, 'RDOOM_FRAG_NQ': '1'})
+    bad, _ = run_child({'frag_bw': bw, 'frag_nq': 1})
     assert bad == 0
 
 
