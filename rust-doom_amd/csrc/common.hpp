@@ -20,8 +20,6 @@ struct DebugOptions {
   int frag_bw = 3;       // log2(units per row of the fragment kernel's wave block)
   int frag_chunk = 0;    // wave blocks per wave in the fragment kernel (0 = default)
   int bin_threads = 256; // workgroup size of the binning kernel
-  int defer_all = 0;     // the rasteriser defers every entry: the repair kernel resolves the whole frame
-  int defer_cap = 0;     // deferred pairs a tile may list (0 = default 64), to force the replay of whole tile lists
   int no_cover = 0;      // no depth-only body for quadrant-covering triangles
   int raster_stats = 0;  // census of the rasteriser's paths on stderr (instrumented instantiation: slower)
 };

@@ -24,14 +24,11 @@ void launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, c
 bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
                 uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
                 uint32_t *overflow);
-// Kernels 2 + 2b: tiled rasteriser -> visibility words, then the repair of what it deferred (raster.hip)
+// Kernel 2: tiled rasteriser -> visibility words (raster.hip)
 rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
-                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out, uint32_t *repair_count,
-                           void *repair_store, uint32_t max_poses);
-// bytes of the repair store (one item + one pair list per (pose, tile)) launch_raster needs
-size_t raster_repair_bytes(uint32_t max_poses, uint32_t n_tiles);
+                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out);
 // Kernels 3 + 4: fragment kernel -> palette indices, then the alpha-leak fixup (fragment.hip)
 rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                              const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,

@@ -19,103 +19,179 @@ namespace rdoom_dev {
 namespace {
 
 // =================================================================================================
-// Rasteriser.  Two kernels:
-//   raster_wave_kernel    the hot one: per (pose, 64x64 tile) it walks the tile's near-to-far list with two straight-line
-//                         pixel bodies only (depth-only for triangles covering a quadrant, a 16-instruction body for the
-//                         rest).  Whatever needs the exact general rule -- interior-masked textures (alpha test before
-//                         the depth write: static.frag:21, sprite.frag:20), blocks crossing the near / far plane or the
-//                         w = 0 line, edge and depth ties -- is DEFERRED: the wave notes (quadrant, record) in a
-//                         per-tile list instead of resolving it.
-//   raster_repair_kernel  one wave per tile that deferred anything: rebuilds the quadrant's depths from the visibility
-//                         words (the winner's depth plane, same arithmetic), applies the deferred entries with the
-//                         general per-pixel body (R1..R6) and rewrites the words.
-// The winner of a pixel is the lexicographic minimum of (d24, primitive id) over its passing fragments, so it does not
-// depend on the order in which fragments are applied: the hot kernel applies a subset of the passing fragments, the
-// repair kernel the rest (re-applying one is harmless).  Early-z in the hot kernel stays exact: depths only get nearer.
-// Rejection is hierarchical and exact: fmaf is monotone in each argument, so the extreme of a *computed* edge
-// function, depth plane or 1/w plane over a pixel rectangle sits at a corner.
+// Rasteriser, per-entry part.  Rejection is hierarchical and exact: fmaf is monotone in each argument, so the
+// extreme of a *computed* edge function, depth plane or 1/w plane over a pixel rectangle sits at a corner --
+// per lane: nearest-corner depth against the lane's farthest pixel (early-z) first, then three edge corners,
+// the depth range and the 1/w plane.  One __any() skips the 16-pixel body when no lane needs it.
+// Winner = lexicographic min of (d24, primitive id): independent of processing order.
 // =================================================================================================
-constexpr uint32_t DEFER_CAP = 64;          // deferred (quadrant, record) pairs a tile can list; more: the whole tile list is replayed
-constexpr uint32_t DEFER_ALL = 0xFFFFFFFFu;
-
-// One queue entry against one lane's 4x4 block: exact rejection (early-z first), then the fast pixel body.
+// One queue entry against one lane's 4x4 block: exact rejection (early-z first), then the pixel bodies (R1..R6).
 // The coefficients arrive wave-uniform (v_readlane broadcasts), i.e. as SGPR operands.
-// Returns true for a lane whose block needs the general body for this entry (deferred to the repair kernel).
-template <bool STATS>
-__device__ __forceinline__ bool raster_entry_fast(float e0a, float e0b, float e0c, float e1a, float e1b, float e1c, float e2a,
-                                                  float e2b, float e2c, float za, float zb, float zc, float wa, float wb,
-                                                  float wc, int x0, int y0, int x1, int y1, uint32_t ridx, int bx, int by,
-                                                  float pxlo, float pxhi, float pylo, float pyhi, uint32_t (&best_d)[16],
-                                                  uint32_t (&best_r)[16], uint32_t &lane_far,
-                                                  unsigned long long (&st)[16]) {
-  // lane-level exact rejection over my 4x4 block.  Early-z first (most rejected triangles are simply hidden):
-  // nearest depth of the plane over the block against the farthest depth I still hold
-  const float zn = fmaf(za, pos(za) ? pxlo : pxhi, fmaf(zb, pos(zb) ? pylo : pyhi, zc));
-  const uint32_t dn = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
-  const bool zpass = (zn <= 1.0f) & (dn <= lane_far);
-  if (!__any(zpass)) {
-    if (STATS) st[15]++;
-    return false;
-  }
-  // largest edge values and farthest depth
-  const float m0 = fmaf(e0a, pos(e0a) ? pxhi : pxlo, fmaf(e0b, pos(e0b) ? pyhi : pylo, e0c));
-  const float m1 = fmaf(e1a, pos(e1a) ? pxhi : pxlo, fmaf(e1b, pos(e1b) ? pyhi : pylo, e1c));
-  const float m2 = fmaf(e2a, pos(e2a) ? pxhi : pxlo, fmaf(e2b, pos(e2b) ? pyhi : pylo, e2c));
-  const float zf = fmaf(za, pos(za) ? pxhi : pxlo, fmaf(zb, pos(zb) ? pyhi : pylo, zc));
-  const bool need0 = zpass && bx <= x1 && bx + 3 >= x0 && by <= y1 && by + 3 >= y0 && m0 >= 0.0f && m1 >= 0.0f &&
-                     m2 >= 0.0f && zf >= 0.0f;
-  if (STATS && !__any(need0)) st[14]++;
-  if (!__any(need0)) return false;
-  // R3 needs rw > 0: a block whose largest 1/w is not positive holds no coverable pixel (same corner argument)
-  const float rwf = fmaf(wa, pos(wa) ? pxhi : pxlo, fmaf(wb, pos(wb) ? pyhi : pylo, wc));
-  const bool need = need0 & (rwf > 0.0f);
-  if (!__any(need)) return false;
-  if (STATS) st[2]++, st[3] += (unsigned long long)__popcll(__ballot(need));
-  // Fast body (exact where it applies): whole block inside the depth range and in front of the eye.  Edge ties and
-  // depth ties are only *detected* here; the block is then deferred.
-  // A texture whose only transparent texels lie in the one-texel ring around its rectangle (RASTER_MASKED_BORDER)
-  // is treated as opaque here; the rare pixel whose float mod lands on the ring is caught by the fragment kernel
-  // (it sees a transparent texel) and re-resolved by fixup_kernel.
-  const float rwn = fmaf(wa, pos(wa) ? pxlo : pxhi, fmaf(wb, pos(wb) ? pylo : pyhi, wc));
-  const bool fast = need & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f);
-  // pixels of my block outside the triangle's bbox (S6) never win: bit k of `outside` (k = 4 * row + column).
-  // need guarantees the block overlaps the bbox, so the column and row ranges below are non-empty.
-  uint32_t outside = 0u;
-  if (__any(fast & !((bx >= x0) & (bx + 3 <= x1) & (by >= y0) & (by + 3 <= y1)))) {
-    const int clo = max(x0 - bx, 0), chi = min(x1 - bx, 3), rlo = max(y0 - by, 0), rhi = min(y1 - by, 3);
-    const uint32_t cm = ((2u << chi) - 1u) & ~((1u << clo) - 1u);                // columns inside, 4 bits
-    const uint32_t rows = ((16u << (4 * rhi)) - 1u) & ~((1u << (4 * rlo)) - 1u);  // all pixels of the rows inside
-    outside = ~((cm * 0x1111u) & rows) & 0xFFFFu;
-  }
-  // Ties are folded into ONE unsigned minimum so that no per-pixel compare mask has to stay alive (sixteen of them
-  // do not fit the scalar registers): tiez = 0 iff some pixel has an edge function exactly zero, or lies inside with a
-  // depth equal to the one it holds.  d24m - best is computed once; its borrow is the depth test.
-  uint32_t tiez = NONE;
-  bool updated = false;
-  if (STATS && __any(fast)) st[4]++, st[5] += (unsigned long long)__popcll(__ballot(fast));
-  if (fast) {
+template <bool STATS, class ShadeFetch>
+__device__ __forceinline__ void raster_entry(const DeviceLevelView &lv, const TriRec *__restrict__ prec, float e0a, float e0b,
+                                             float e0c, float e1a, float e1b, float e1c, float e2a, float e2b, float e2c,
+                                             float za, float zb, float zc, float wa, float wb, float wc, int x0, int y0,
+                                             int x1, int y1, uint32_t flags, uint32_t ridx, int bx, int by, float pxlo,
+                                             float pxhi, float pylo, float pyhi, uint32_t (&best_d)[16],
+                                             uint32_t (&best_r)[16], uint32_t &lane_far, ShadeFetch fetch_shade,
+                                             unsigned long long (&st)[16]) {
+    // lane-level exact rejection over my 4x4 block.  Early-z first (most rejected triangles are simply hidden):
+    // nearest depth of the plane over the block against the farthest depth I still hold
+    const float zn = fmaf(za, pos(za) ? pxlo : pxhi, fmaf(zb, pos(zb) ? pylo : pyhi, zc));
+    const uint32_t dn = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
+    const bool zpass = (zn <= 1.0f) & (dn <= lane_far);
+    if (!__any(zpass)) {
+      if (STATS) st[15]++;
+      return;
+    }
+    // largest edge values and farthest depth
+    const float m0 = fmaf(e0a, pos(e0a) ? pxhi : pxlo, fmaf(e0b, pos(e0b) ? pyhi : pylo, e0c));
+    const float m1 = fmaf(e1a, pos(e1a) ? pxhi : pxlo, fmaf(e1b, pos(e1b) ? pyhi : pylo, e1c));
+    const float m2 = fmaf(e2a, pos(e2a) ? pxhi : pxlo, fmaf(e2b, pos(e2b) ? pyhi : pylo, e2c));
+    const float zf = fmaf(za, pos(za) ? pxhi : pxlo, fmaf(zb, pos(zb) ? pyhi : pylo, zc));
+    const bool need0 = zpass && bx <= x1 && bx + 3 >= x0 && by <= y1 && by + 3 >= y0 && m0 >= 0.0f && m1 >= 0.0f &&
+                       m2 >= 0.0f && zf >= 0.0f;
+    if (STATS && !__any(need0)) st[14]++;
+    if (!__any(need0)) return;
+    // R3 needs rw > 0: a block whose largest 1/w is not positive holds no coverable pixel (same corner argument)
+    const float rwf = fmaf(wa, pos(wa) ? pxhi : pxlo, fmaf(wb, pos(wb) ? pyhi : pylo, wc));
+    const bool need = need0 & (rwf > 0.0f);
+    if (!__any(need)) return;
+    if (STATS) st[2]++, st[3] += (unsigned long long)__popcll(__ballot(need));
+    // Fast path (exact): block fully inside the bbox, whole block inside the depth range and in front
+    // of the eye, texture rectangle fully opaque.  Edge ties and depth ties are only *detected* here and
+    // replayed through the general path below, so the result is the same as running it everywhere.
+    // A texture whose only transparent texels lie in the one-texel ring around its rectangle
+    // (RASTER_MASKED_BORDER) is treated as opaque here; the rare pixel whose float mod lands on the ring
+    // is caught by the fragment kernel (it sees a transparent texel) and re-resolved by fixup_kernel.
+    const float rwn = fmaf(wa, pos(wa) ? pxlo : pxhi, fmaf(wb, pos(wb) ? pylo : pyhi, wc));
+    const bool fast = need & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) & ((flags & RASTER_MASKED_INTERIOR) == 0u);
+    // pixels of my block outside the triangle's bbox (S6) never win: bit k of `outside` (k = 4 * row + column).
+    // need guarantees the block overlaps the bbox, so the column and row ranges below are non-empty.
+    uint32_t outside = 0u;
+    if (__any(fast & !((bx >= x0) & (bx + 3 <= x1) & (by >= y0) & (by + 3 <= y1)))) {
+      const int clo = max(x0 - bx, 0), chi = min(x1 - bx, 3), rlo = max(y0 - by, 0), rhi = min(y1 - by, 3);
+      const uint32_t cm = ((2u << chi) - 1u) & ~((1u << clo) - 1u);                // columns inside, 4 bits
+      const uint32_t rows = ((16u << (4 * rhi)) - 1u) & ~((1u << (4 * rlo)) - 1u);  // all pixels of the rows inside
+      outside = ~((cm * 0x1111u) & rows) & 0xFFFFu;
+    }
+    // Ties are folded into ONE unsigned minimum so that no per-pixel compare mask has to stay alive (sixteen of them
+    // do not fit the scalar registers): tiez = 0 iff some pixel has an edge function exactly zero, or lies inside with
+    // a depth equal to the one it holds.  d24m - best is computed once; its borrow is the depth test.
+    uint32_t tiez = NONE;
+    bool updated = false;
+    if (STATS && __any(fast)) st[4]++, st[5] += (unsigned long long)__popcll(__ballot(fast));
+    if (fast) {
 #pragma unroll
-    for (int ry = 0; ry < 4; ry++) {
-      const float py = pylo + (float)ry;
-      const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
-      const float tz = fmaf(zb, py, zc);
+      for (int ry = 0; ry < 4; ry++) {
+        const float py = pylo + (float)ry;
+        const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
+        const float tz = fmaf(zb, py, zc);
 #pragma unroll
-      for (int rx = 0; rx < 4; rx++) {
-        const int k = ry * 4 + rx;
-        const float px = pxlo + (float)rx;
-        const float em = fminf(fminf(fmaf(e0a, px, t0), fmaf(e1a, px, t1)), fmaf(e2a, px, t2));
-        const uint32_t d24 = __float2uint_rz(fmaf(fmaf(za, px, tz), 16777215.0f, 0.5f));
-        const uint32_t d24m = d24 | (uint32_t)__builtin_amdgcn_sbfe((int)outside, k, 1);  // all ones when outside
-        uint32_t diff;
-        const bool nearer = __builtin_usub_overflow(d24m, best_d[k], &diff);  // borrow: d24m < best_d[k]
-        const int ei = (int)__float_as_uint(em);
-        const bool inside = ei > 0;  // em > 0
-        // inside: zero iff the depths are equal; not inside: zero iff em is +0 or -0 (an edge tie)
-        tiez = min(tiez, inside ? diff : ((uint32_t)ei << 1));
-        const bool win = inside & nearer;
-        best_d[k] = win ? d24 : best_d[k];
-        best_r[k] = win ? ridx : best_r[k];
-        updated |= win;
+        for (int rx = 0; rx < 4; rx++) {
+          const int k = ry * 4 + rx;
+          const float px = pxlo + (float)rx;
+          const float em = fminf(fminf(fmaf(e0a, px, t0), fmaf(e1a, px, t1)), fmaf(e2a, px, t2));
+          const uint32_t d24 = __float2uint_rz(fmaf(fmaf(za, px, tz), 16777215.0f, 0.5f));
+          const uint32_t d24m = d24 | (uint32_t)__builtin_amdgcn_sbfe((int)outside, k, 1);  // all ones when outside
+          uint32_t diff;
+          const bool nearer = __builtin_usub_overflow(d24m, best_d[k], &diff);  // borrow: d24m < best_d[k]
+          const int ei = (int)__float_as_uint(em);
+          const bool inside = ei > 0;  // em > 0
+          // inside: zero iff the depths are equal; not inside: zero iff em is +0 or -0 (an edge tie)
+          tiez = min(tiez, inside ? diff : ((uint32_t)ei << 1));
+          const bool win = inside & nearer;
+          best_d[k] = win ? d24 : best_d[k];
+          best_r[k] = win ? ridx : best_r[k];
+          updated |= win;
+        }
+      }
+    }
+    const bool redo = tiez == 0u;
+    if (__any(need & (!fast | redo))) {
+      if (STATS) {
+        st[6]++, st[7] += (unsigned long long)__popcll(__ballot(need & (!fast | redo)));
+        // why: [12] masked texture, [13] tie replay
+        st[12] += (unsigned long long)__popcll(__ballot(need & ((flags & RASTER_MASKED_INTERIOR) != 0u)));
+        st[13] += (unsigned long long)__popcll(__ballot(need & fast & redo));
+      }
+      if (need & (!fast | redo)) {
+        // The general rule R1..R6, a row of four pixels at a time and branch-free but for two rare cases (a depth tie
+        // that the primitive order must settle; texels to look at): compare results go straight into bit masks.
+        const uint32_t prim = flags & 0xFFFFFFu;
+        const bool tl0 = (flags & (1u << 24)) != 0u, tl1 = (flags & (1u << 25)) != 0u, tl2 = (flags & (1u << 26)) != 0u;
+        const bool masked = (flags & RASTER_MASKED_ANY) != 0u, interior = (flags & RASTER_MASKED_INTERIOR) != 0u;  // uniform
+        ShadeRec sh;
+        if (masked) sh = fetch_shade();
+#pragma unroll
+        for (int ry = 0; ry < 4; ry++) {
+          const int iy = by + ry;
+          const float py = pylo + (float)ry;  // == (float)iy + 0.5f exactly
+          const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
+          const float tz = fmaf(zb, py, zc), tw = fmaf(wb, py, wc);
+          const bool rowin = iy >= y0 && iy <= y1;
+          uint32_t passm = 0u, tiem = 0u, d24s[4];
+#pragma unroll
+          for (int rx = 0; rx < 4; rx++) {
+            const int ix = bx + rx;
+            const float px = pxlo + (float)rx;  // == (float)ix + 0.5f exactly
+            const float e0 = fmaf(e0a, px, t0), e1 = fmaf(e1a, px, t1), e2 = fmaf(e2a, px, t2);
+            const bool in0 = (e0 > 0.0f) | ((e0 == 0.0f) & tl0);
+            const bool in1 = (e1 > 0.0f) | ((e1 == 0.0f) & tl1);
+            const bool in2 = (e2 > 0.0f) | ((e2 == 0.0f) & tl2);
+            const float zw = fmaf(za, px, tz);
+            const float rw = fmaf(wa, px, tw);
+            const uint32_t d24 = __float2uint_rz(fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f));
+            const uint32_t bd = ry == 0 ? best_d[rx] : (ry == 1 ? best_d[4 + rx] : (ry == 2 ? best_d[8 + rx] : best_d[12 + rx]));
+            const bool geom = rowin & (ix >= x0) & (ix <= x1) & in0 & in1 & in2 & (zw >= 0.0f) & (zw <= 1.0f) & (rw > 0.0f);
+            d24s[rx] = d24;
+            passm |= (geom & (d24 < bd)) ? (1u << rx) : 0u;
+            tiem |= (geom & (d24 == bd)) ? (1u << rx) : 0u;
+          }
+          if (tiem != 0u) {  // depth tie (rare): the earlier primitive keeps the pixel
+#pragma unroll
+            for (int rx = 0; rx < 4; rx++)
+              if ((tiem >> rx) & 1u) {
+                const uint32_t br = ry == 0 ? best_r[rx] : (ry == 1 ? best_r[4 + rx] : (ry == 2 ? best_r[8 + rx] : best_r[12 + rx]));
+                if (br == NONE || prim < (prec[br].r.flags & 0xFFFFFFu)) passm |= 1u << rx;
+              }
+          }
+          if (masked && passm != 0u) {  // R6: alpha test before the depth write; the row's texel fetches in flight together
+            const float tu = fmaf(sh.up[1], py, sh.up[2]), tv = fmaf(sh.vp[1], py, sh.vp[2]);
+            uint32_t toff[4], fetchm = 0u;
+#pragma unroll
+            for (int rx = 0; rx < 4; rx++) {
+              // pixels that did not pass compute garbage coordinates: the offset stays inside the texel store, the result is ignored
+              const TexelAt t = texel_coords(sh, pxlo + (float)rx, tw, tu, tv);
+              // texture rectangle fully opaque: only a coordinate that the float mod pushed just outside the rectangle
+              // can hit a transparent neighbour texel -- look only then
+              const bool must_fetch = interior | (t.ix < (int)sh.atlas_u) | (t.ix >= (int)(sh.atlas_u + sh.size_x)) |
+                                      (t.iy < (int)sh.atlas_v) | (t.iy >= (int)(sh.atlas_v + sh.size_y));
+              toff[rx] = texel_offset(sh.flags, sh.tex, t.ix, t.iy);
+              fetchm |= must_fetch ? (1u << rx) : 0u;
+            }
+            fetchm &= passm;
+            if (fetchm != 0u) {
+              uint32_t tx[4];
+#pragma unroll
+              for (int rx = 0; rx < 4; rx++) tx[rx] = lv.texels[toff[rx]];
+#pragma unroll
+              for (int rx = 0; rx < 4; rx++)
+                if (tx[rx] & 0x8000u) passm &= ~(fetchm & (1u << rx));
+            }
+          }
+          updated |= passm != 0u;
+#pragma unroll
+          for (int rx = 0; rx < 4; rx++) {
+            const bool pass = ((passm >> rx) & 1u) != 0u;
+#pragma unroll
+            for (int r2 = 0; r2 < 4; r2++)
+              if (r2 == ry) {
+                best_d[r2 * 4 + rx] = pass ? d24s[rx] : best_d[r2 * 4 + rx];
+                best_r[r2 * 4 + rx] = pass ? ridx : best_r[r2 * 4 + rx];
+              }
+          }
+        }
       }
     }
     if (updated) {
@@ -124,84 +200,6 @@ __device__ __forceinline__ bool raster_entry_fast(float e0a, float e0b, float e0
       for (int k = 1; k < 16; k++) m = max(m, best_d[k]);
       lane_far = m;
     }
-  }
-  const bool redo = tiez == 0u;
-  const bool defer = need & (!fast | redo);
-  if (STATS && __any(defer)) {
-    st[6]++, st[7] += (unsigned long long)__popcll(__ballot(defer));
-    st[13] += (unsigned long long)__popcll(__ballot(need & fast & redo));
-  }
-  return defer;
-}
-
-// The general per-pixel rule R1..R6 for one record over one lane's 4x4 block, on top of (best_d, best_r): coverage with
-// the tie flags, bbox, depth range, rw > 0, depth LESS with the earlier primitive keeping ties, alpha test before the
-// depth write.  Coefficients are wave-uniform.
-__device__ __forceinline__ void raster_entry_general(const DeviceLevelView &lv, const TriRec *__restrict__ prec,
-                                                     const RasterRec &r, uint32_t ridx, int bx, int by,
-                                                     uint32_t (&best_d)[16], uint32_t (&best_r)[16]) {
-  const float pxlo = (float)bx + 0.5f, pxhi = (float)bx + 3.5f, pylo = (float)by + 0.5f, pyhi = (float)by + 3.5f;
-  const int x0 = (int)(r.bb0 & 0xFFFFu), y0 = (int)(r.bb0 >> 16), x1 = (int)(r.bb1 & 0xFFFFu), y1 = (int)(r.bb1 >> 16);
-  const float e0a = r.e[0], e0b = r.e[1], e0c = r.e[2], e1a = r.e[3], e1b = r.e[4], e1c = r.e[5], e2a = r.e[6], e2b = r.e[7],
-              e2c = r.e[8], za = r.zp[0], zb = r.zp[1], zc = r.zp[2], wa = r.wp[0], wb = r.wp[1], wc = r.wp[2];
-  const uint32_t flags = r.flags;
-  // exact block-level rejection (corner arguments), incl. early-z against the farthest depth the block still holds
-  uint32_t far = best_d[0];
-#pragma unroll
-  for (int k = 1; k < 16; k++) far = max(far, best_d[k]);
-  const float zn = fmaf(za, pos(za) ? pxlo : pxhi, fmaf(zb, pos(zb) ? pylo : pyhi, zc));
-  const float zf = fmaf(za, pos(za) ? pxhi : pxlo, fmaf(zb, pos(zb) ? pyhi : pylo, zc));
-  const uint32_t dn = __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f));
-  const float m0 = fmaf(e0a, pos(e0a) ? pxhi : pxlo, fmaf(e0b, pos(e0b) ? pyhi : pylo, e0c));
-  const float m1 = fmaf(e1a, pos(e1a) ? pxhi : pxlo, fmaf(e1b, pos(e1b) ? pyhi : pylo, e1c));
-  const float m2 = fmaf(e2a, pos(e2a) ? pxhi : pxlo, fmaf(e2b, pos(e2b) ? pyhi : pylo, e2c));
-  const float rwf = fmaf(wa, pos(wa) ? pxhi : pxlo, fmaf(wb, pos(wb) ? pyhi : pylo, wc));
-  const bool need = (zn <= 1.0f) & (dn <= far) & (bx <= x1) & (bx + 3 >= x0) & (by <= y1) & (by + 3 >= y0) & (m0 >= 0.0f) &
-                    (m1 >= 0.0f) & (m2 >= 0.0f) & (zf >= 0.0f) & (rwf > 0.0f);
-  if (!need) return;
-  const uint32_t prim = flags & 0xFFFFFFu;
-  ShadeRec sh;
-  const bool masked = (flags & RASTER_MASKED_ANY) != 0u;
-  if (masked) sh = prec[ridx].s;
-#pragma unroll 1
-  for (int ry = 0; ry < 4; ry++) {
-    const int iy = by + ry;
-    const float py = pylo + (float)ry;  // == (float)iy + 0.5f exactly
-    const float t0 = fmaf(e0b, py, e0c), t1 = fmaf(e1b, py, e1c), t2 = fmaf(e2b, py, e2c);
-    const float tz = fmaf(zb, py, zc), tw = fmaf(wb, py, wc);
-    const bool rowin = iy >= y0 && iy <= y1;
-#pragma unroll
-    for (int rx = 0; rx < 4; rx++) {
-      const int ix = bx + rx;
-      const float px = pxlo + (float)rx;  // == (float)ix + 0.5f exactly
-      const float e0 = fmaf(e0a, px, t0), e1 = fmaf(e1a, px, t1), e2 = fmaf(e2a, px, t2);
-      const bool in0 = (e0 > 0.0f) | ((e0 == 0.0f) & ((flags & (1u << 24)) != 0u));
-      const bool in1 = (e1 > 0.0f) | ((e1 == 0.0f) & ((flags & (1u << 25)) != 0u));
-      const bool in2 = (e2 > 0.0f) | ((e2 == 0.0f) & ((flags & (1u << 26)) != 0u));
-      const float zw = fmaf(za, px, tz);
-      const float rw = fmaf(wa, px, tw);
-      const uint32_t d24 = __float2uint_rz(fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f));
-      const int k = ry * 4 + rx;
-      const uint32_t bd = best_d[k], br = best_r[k];
-      bool pass = rowin & (ix >= x0) & (ix <= x1) & in0 & in1 & in2 & (zw >= 0.0f) & (zw <= 1.0f) & (rw > 0.0f) &
-                  (d24 <= bd);
-      if (pass && d24 == bd)  // depth tie (rare): the earlier primitive keeps the pixel
-        pass = br == NONE || prim < (prec[br].r.flags & 0xFFFFFFu);
-      if (pass && masked) {  // R6: alpha test before the depth write
-        const TexelAt t = texel_coords(sh, px, tw, fmaf(sh.up[1], py, sh.up[2]), fmaf(sh.vp[1], py, sh.vp[2]));
-        // texture rectangle fully opaque: only a coordinate that the float mod pushed just outside
-        // the rectangle can hit a transparent neighbour texel -- fetch only then
-        const bool must_fetch = (flags & RASTER_MASKED_INTERIOR) != 0u || t.ix < (int)sh.atlas_u ||
-                                t.ix >= (int)(sh.atlas_u + sh.size_x) || t.iy < (int)sh.atlas_v ||
-                                t.iy >= (int)(sh.atlas_v + sh.size_y);
-        if (must_fetch) pass = (load_texel(lv, sh, t.ix, t.iy) & 0x8000u) == 0u;
-      }
-      if (pass) {
-        best_d[k] = d24;
-        best_r[k] = ridx;
-      }
-    }
-  }
 }
 
 // =================================================================================================
@@ -218,15 +216,9 @@ __device__ __forceinline__ void raster_entry_general(const DeviceLevelView &lv, 
 //   * walk        per quadrant, entry s is broadcast with v_readlane / uniform LDS reads: its coefficients become
 //                 wave-uniform SGPR operands.  One compare against the lanes' farthest depths skips a hidden
 //                 triangle before anything else is touched (most rejections are of this kind); a covering
-//                 triangle runs a depth-only pixel body;
-//   * deferral    see the header of this file: (quadrant, record) pairs for the repair kernel, kept in a per-wave LDS
-//                 list and written out once per tile.
+//                 triangle runs a depth-only pixel body.
 // A tile with more than 64 entries re-gathers each 64-entry batch once per quadrant.
 // =================================================================================================
-struct RepairItem {   // 16 bytes: one tile that deferred something
-  uint32_t pose, tile, n_deferred /* or DEFER_ALL */, pad;
-};
-
 template <bool STATS>
 __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                              const uint4 *__restrict__ sorted,
@@ -236,15 +228,11 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
                                                              const uint32_t *__restrict__ entries, uint32_t entry_cap,
                                                              const uint32_t *__restrict__ overflow,
                                                              uint32_t *__restrict__ vis, uint32_t vis16,
-                                                             uint32_t *__restrict__ prim_out,
-                                                             uint32_t *__restrict__ repair_count,
-                                                             RepairItem *__restrict__ repair_items,
-                                                             uint32_t *__restrict__ repair_pool, uint32_t defer_mode,
+                                                             uint32_t *__restrict__ prim_out, uint32_t no_cover,
                                                              unsigned long long *__restrict__ stats) {
   unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __shared__ uint32_t wq[4][64];
   __shared__ uint4 wrec[4][64][4];  // per wave: 15 words of each of the 64 gathered raster records
-  __shared__ uint32_t wdefer[4][DEFER_CAP];
   const uint32_t b = blockIdx.x;
   const uint32_t T = (uint32_t)(tiles_x * tiles_y), T4 = (T + 3u) >> 2;
   const uint32_t g = b >> 3;
@@ -262,14 +250,6 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
   const uint32_t count = hdr.y;
   const bool single = count <= 64u;  // the usual case: one gather serves all four quadrants
   uint32_t *myq = wq[wave];
-  uint32_t ndef = 0;                 // deferred pairs of this tile (wave-uniform)
-  const uint32_t defer_cap = (defer_mode >> 8) ? min(DEFER_CAP, defer_mode >> 8) : DEFER_CAP;  // tests: force the overflow
-  const bool defer_everything = (defer_mode & 1u) != 0u;                                       // tests: all through the repair
-  const bool no_cover = (defer_mode & 2u) != 0u;                                               // tests: no depth-only body
-  auto push_deferred = [&](uint32_t q, uint32_t ridx) {
-    if (ndef < defer_cap && lane == 0) wdefer[wave][ndef] = (q << 28) | ridx;
-    ndef++;
-  };
   // what lane s keeps of the s-th entry of the current batch: record index, quadrant bits (touches: 0..3, covers:
   // 4..7), the depth plane, the nearest depth over each quadrant
   uint32_t n = 0, myrec = 0, myqb = 0, zpa = 0, zpb = 0, zpc = 0, dnq0 = NONE, dnq1 = NONE, dnq2 = NONE, dnq3 = NONE;
@@ -358,10 +338,8 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
               const bool cov = (n0 > 0.0f) & (n1 > 0.0f) & (n2 > 0.0f) & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) &
                                (x0 <= rx0) & (x1 >= rx0 + 31) & (y0 <= ry0) & (y1 >= ry0 + 31) &
                                ((c4.y & RASTER_MASKED_INTERIOR) == 0u);
-              myqb |= (cov && !no_cover) ? (16u << qi) : 0u;
+              myqb |= (cov && !no_cover) ? (16u << qi) : 0u;  // no_cover: test hook
             }
-            // bit 8: the entry's fragments need the alpha test (deferred without looking at blocks)
-            myqb |= ((c4.y & RASTER_MASKED_INTERIOR) != 0u || defer_everything) ? 256u : 0u;
             dnq0 = dn[0], dnq1 = dn[1], dnq2 = dn[2], dnq3 = dn[3];
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -371,7 +349,6 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
       // ---- walk: the entries that touch this quadrant, near to far -------------------------------------------
       const uint32_t dnq = q == 0 ? dnq0 : (q == 1 ? dnq1 : (q == 2 ? dnq2 : dnq3));
       const unsigned long long qcm = __ballot(((myqb >> (4 + q)) & 1u) != 0u);
-      const unsigned long long mkm = __ballot((myqb & 256u) != 0u);
       for (unsigned long long wm = __ballot(((myqb >> q) & 1u) != 0u); wm; wm &= wm - 1ull) {
         const uint32_t s = (uint32_t)__builtin_ctzll(wm);
         if (STATS) st[0]++;
@@ -384,17 +361,12 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
         if (STATS) st[1]++;
         auto bc = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)s); };
         auto bf = [&](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, (int)s)); };
-        const uint32_t ridx = bc(myrec);
-        if ((mkm >> s) & 1ull) {  // alpha-tested fragments: the repair kernel's business
-          if (STATS) st[12]++;
-          push_deferred((uint32_t)q, ridx);
-          continue;
-        }
         const float za = bf(zpa), zb = bf(zpb), zc = bf(zpc);
+        const uint32_t ridx = bc(myrec);
         if ((qcm >> s) & 1ull) {
           // the triangle covers the whole quadrant, inside its bbox, the depth range and in front of the eye, texture
           // rectangle opaque: depth compares only.  (Lanes whose block is hidden lose every compare.)  A depth tie
-          // defers the entry: the repair kernel re-resolves the quadrant exactly.
+          // is replayed through the regular path below, which re-resolves the block exactly.
           if (STATS) st[10]++;
           uint32_t tiez = NONE;  // min over the block of (d24 - best): zero iff some depth ties
           bool updated = false;
@@ -419,21 +391,18 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
             for (int k = 1; k < 16; k++) m = max(m, best_d[k]);
             lane_far = m;
           }
-          const bool tie = tiez == 0u;
-          if (__any(tie)) push_deferred((uint32_t)q, ridx);
-          continue;
+          if (!__any(tiez == 0u)) continue;
         }
         // the rest of the record: uniform LDS reads, made SGPR operands
         const uint4 *wr = wrec[wave][s];
         const uint4 r0 = wr[0], r1 = wr[1], r2 = wr[2], r3 = wr[3];
         auto uf = [](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)v)); };
         auto uu = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-        const uint32_t bb0 = uu(r2.w), bb1 = uu(r3.y);
+        const uint32_t bb0 = uu(r2.w), bb1 = uu(r3.y), flags = uu(r3.z);
         const int x0 = (int)(bb0 & 0xFFFFu), y0 = (int)(bb0 >> 16), x1 = (int)(bb1 & 0xFFFFu), y1 = (int)(bb1 >> 16);
-        const bool defer = raster_entry_fast<STATS>(uf(r0.x), uf(r0.y), uf(r0.z), uf(r0.w), uf(r1.x), uf(r1.y), uf(r1.z), uf(r1.w),
-                                                    uf(r3.x), za, zb, zc, uf(r2.x), uf(r2.y), uf(r2.z), x0, y0, x1, y1, ridx, bx,
-                                                    by, pxlo, pxhi, pylo, pyhi, best_d, best_r, lane_far, st);
-        if (__any(defer)) push_deferred((uint32_t)q, ridx);
+        raster_entry<STATS>(lv, prec, uf(r0.x), uf(r0.y), uf(r0.z), uf(r0.w), uf(r1.x), uf(r1.y), uf(r1.z), uf(r1.w),
+                                 uf(r3.x), za, zb, zc, uf(r2.x), uf(r2.y), uf(r2.z), x0, y0, x1, y1, flags, ridx, bx, by, pxlo,
+                                 pxhi, pylo, pyhi, best_d, best_r, lane_far, [&]() -> ShadeRec { return prec[ridx].s; }, st);
       }
     }
     // ---- this quadrant's visibility words ------------------------------------------------------------------------
@@ -461,153 +430,20 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
       }
     }
   }
-  // ---- this tile's deferred pairs, for the repair kernel --------------------------------------------------------
-  if (ndef != 0u) {
-    uint32_t slot = 0;
-    if (lane == 0) slot = atomicAdd(repair_count, 1u);
-    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);  // < n_poses * T: one slot per tile exists
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane == 0) repair_items[slot] = RepairItem{pose, tile, ndef <= defer_cap ? ndef : DEFER_ALL, 0u};
-    if ((uint32_t)lane < min(ndef, defer_cap)) repair_pool[(size_t)slot * DEFER_CAP + (uint32_t)lane] = wdefer[wave][lane];
-    if (STATS) st[11] += ndef;
-  }
   if (STATS && lane == 0)
     for (int k = 0; k < 16; k++) atomicAdd(&stats[k], st[k]);
 }
 
-// =================================================================================================
-// Kernel 2b: repair.  One wave per RepairItem (persistent over the list).  Per quadrant with deferred pairs: each lane
-// reads its 4x4 visibility words, recomputes every winner's d24 from the winner's depth plane (R2, R4 -- the arithmetic
-// the hot kernel used), applies the deferred records with the general body and rewrites the words.
-// =================================================================================================
-__global__ __launch_bounds__(256) void raster_repair_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
-                                                            const uint4 *__restrict__ sorted,
-                                                            const uint32_t *__restrict__ counts, uint32_t cap, int width,
-                                                            int height, int tiles_x, int tiles_y,
-                                                            const uint2 *__restrict__ tile_hdr,
-                                                            const uint32_t *__restrict__ entries, uint32_t entry_cap,
-                                                            const uint32_t *__restrict__ overflow,
-                                                            uint32_t *__restrict__ vis, uint32_t vis16,
-                                                            uint32_t *__restrict__ prim_out,
-                                                            const uint32_t *__restrict__ repair_count,
-                                                            const RepairItem *__restrict__ repair_items,
-                                                            const uint32_t *__restrict__ repair_pool) {
-  const uint32_t total = *repair_count;
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
-  const uint32_t T = (uint32_t)(tiles_x * tiles_y);
-  const int lx = (lane & 7) * 4, ly = (lane >> 3) * 4;
-  for (uint32_t item = wave_id; item < total; item += n_waves) {
-    const RepairItem it = repair_items[item];
-    const uint32_t pose = it.pose, tile = it.tile;
-    const TriRec *prec = recs + (size_t)pose * cap;
-    const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE_W, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE_H;
-    const bool all = it.n_deferred == DEFER_ALL;
-    const bool binned = overflow[pose] == 0u;
-    const uint2 hdr = binned ? tile_hdr[(size_t)pose * T + tile] : make_uint2(0u, counts[pose]);
-    const uint32_t n_list = all ? hdr.y : it.n_deferred;
-    const uint32_t *pool = repair_pool + (size_t)item * DEFER_CAP;
-#pragma unroll 1
-    for (int q = 0; q < 4; q++) {
-      const int qx0 = tx0 + (q & 1) * 32, qy0 = ty0 + (q >> 1) * 32;
-      if (qx0 >= width || qy0 >= height) continue;
-      if (!all) {  // anything for this quadrant?
-        bool any = false;
-        for (uint32_t i = 0; i < n_list; i++) any |= (pool[i] >> 28) == (uint32_t)q;
-        if (!any) continue;
-      }
-      const int bx = qx0 + lx, by = qy0 + ly;
-      const bool inframe = bx < width;
-      const float pxlo = (float)bx + 0.5f, pylo = (float)by + 0.5f;
-      const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
-      uint32_t best_d[16], best_r[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) best_d[k] = NONE, best_r[k] = NONE;
-      if (inframe) {
-#pragma unroll
-        for (int ry = 0; ry < 4; ry++) {
-          if (by + ry < height) {
-            const size_t o = o0 + (size_t)(ry * width);
-            if (vis16) {
-              const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(vis) + o);
-              const uint32_t w4[4] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
-#pragma unroll
-              for (int rx = 0; rx < 4; rx++) best_r[ry * 4 + rx] = w4[rx] == 0xFFFFu ? NONE : w4[rx];
-            } else {
-              const uint4 v = *reinterpret_cast<const uint4 *>(vis + o);
-              best_r[ry * 4] = v.x, best_r[ry * 4 + 1] = v.y, best_r[ry * 4 + 2] = v.z, best_r[ry * 4 + 3] = v.w;
-            }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          if (best_r[k] != NONE) {
-            const uint4 c2 = reinterpret_cast<const uint4 *>(&prec[best_r[k]])[2];  // e[8], zp[0..2]
-            const float zw = fmaf(__uint_as_float(c2.y), pxlo + (float)(k & 3),
-                                  fmaf(__uint_as_float(c2.z), pylo + (float)(k >> 2), __uint_as_float(c2.w)));
-            best_d[k] = __float2uint_rz(fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f));
-          }
-        }
-      }
-      for (uint32_t i = 0; i < n_list; i++) {
-        uint32_t ridx;
-        if (all) {  // the pair list overflowed: every entry of the tile (the general body rejects what does not apply)
-          ridx = binned ? (entries[(size_t)pose * entry_cap + hdr.x + i] & 0x0FFFFFFFu) : sorted[(size_t)pose * cap + i].z;
-        } else {
-          const uint32_t e = pool[i];
-          if ((e >> 28) != (uint32_t)q) continue;
-          ridx = e & 0x0FFFFFFFu;
-        }
-        ridx = (uint32_t)__builtin_amdgcn_readfirstlane((int)ridx);
-        const RasterRec r = prec[ridx].r;  // wave-uniform address: scalar loads
-        if (inframe) raster_entry_general(lv, prec, r, ridx, bx, by, best_d, best_r);
-      }
-      if (inframe) {
-#pragma unroll
-        for (int ry = 0; ry < 4; ry++) {
-          if (by + ry < height) {
-            const size_t o = o0 + (size_t)(ry * width);
-            if (vis16)
-              *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) =
-                  make_uint2(__builtin_amdgcn_perm(best_r[ry * 4 + 1], best_r[ry * 4], 0x05040100u),
-                             __builtin_amdgcn_perm(best_r[ry * 4 + 3], best_r[ry * 4 + 2], 0x05040100u));
-            else
-              *reinterpret_cast<uint4 *>(vis + o) =
-                  make_uint4(best_r[ry * 4], best_r[ry * 4 + 1], best_r[ry * 4 + 2], best_r[ry * 4 + 3]);
-            if (prim_out) {
-              uint32_t p[4];
-#pragma unroll
-              for (int rx = 0; rx < 4; rx++)
-                p[rx] = best_r[ry * 4 + rx] == NONE ? NONE : (prec[best_r[ry * 4 + rx]].r.flags & 0xFFFFFFu);
-              *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p[0], p[1], p[2], p[3]);
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
 }  // namespace
-
-size_t raster_repair_bytes(uint32_t max_poses, uint32_t n_tiles) {
-  return (size_t)max_poses * n_tiles * (sizeof(RepairItem) + DEFER_CAP * sizeof(uint32_t));
-}
 
 rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
-                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out, uint32_t *repair_count,
-                           void *repair_store, uint32_t max_poses) {
+                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out) {
   const uint32_t n = n_poses;
-  const uint32_t T = (uint32_t)(tiles_x * tiles_y);
-  const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)((T + 3) / 4);  // four tiles per workgroup
+  const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)((tiles_x * tiles_y + 3) / 4);  // four tiles per workgroup
   if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
-  RepairItem *items = reinterpret_cast<RepairItem *>(repair_store);
-  uint32_t *pool = reinterpret_cast<uint32_t *>(items + (size_t)max_poses * T);
   const rdoom::DebugOptions &dbg = rdoom::debug_options();
-  const uint32_t defer_mode = (dbg.defer_all ? 1u : 0u) | (dbg.no_cover ? 2u : 0u) | ((uint32_t)std::max(0, dbg.defer_cap) << 8);
-  HIP_TRY(hipMemsetAsync(repair_count, 0, sizeof(uint32_t), st));
   unsigned long long *d_stats = nullptr;
   if (dbg.raster_stats) {
     HIP_TRY(hipMalloc((void **)&d_stats, 16 * sizeof(unsigned long long)));
@@ -615,26 +451,20 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
   }
   auto rk = dbg.raster_stats ? raster_wave_kernel<true> : raster_wave_kernel<false>;
   hipLaunchKernelGGL(rk, dim3((uint32_t)nblocks), dim3(256), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
-                     tiles_y, tile_hdr, entries, entry_cap, overflow, vis, vis16 ? 1u : 0u, prim_out, repair_count, items, pool,
-                     defer_mode, d_stats);
-  // persistent over the list: enough waves to fill the chip, few enough that an empty list costs microseconds
-  hipLaunchKernelGGL(raster_repair_kernel, dim3(2048), dim3(256), 0, st, lv, recs, sorted, counts, cap, width, height, tiles_x,
-                     tiles_y, tile_hdr, entries, entry_cap, overflow, vis, vis16 ? 1u : 0u, prim_out, repair_count, items, pool);
+                     tiles_y, tile_hdr, entries, entry_cap, overflow, vis, vis16 ? 1u : 0u, prim_out, dbg.no_cover ? 1u : 0u,
+                     d_stats);
   if (d_stats) {
     unsigned long long h[16];
-    uint32_t n_items = 0;
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&n_items, repair_count, sizeof n_items, hipMemcpyDeviceToHost));
     (void)hipFree(d_stats);
-    const double waves = (double)((n + 7) / 8) * 8.0 * (double)T * 4.0;  // (pose, quadrant) passes
+    const double waves = (double)((n + 7) / 8) * 8.0 * (double)(tiles_x * tiles_y) * 4.0;  // (pose, quadrant) passes
     fprintf(stderr,
             "[rdoom stats] per quadrant pass: queue %.1f  past quadrant early-z %.1f  quadrant-cover %.2f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
-            "  deferred: alpha-tested %.3f, blocks %.3f (lanes %.1f, of them ties %.1f) | rejected: early-z %.2f, then geometry %.2f"
-            " | repair: %u of %.0f tiles, %.2f pairs per repaired tile | coarse tests/block %.0f hits %.1f\n",
+            "  general %.3f (lanes %.1f: masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | coarse tests/block %.0f hits %.1f\n",
             h[0] / waves, h[1] / waves, h[10] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
-            h[4] ? (double)h[5] / h[4] : 0.0, h[12] / waves, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
-            h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, n_items, waves / 4.0,
-            n_items ? (double)h[11] / n_items : 0.0, (double)h[8] / (double)nblocks, (double)h[9] / (double)nblocks);
+            h[4] ? (double)h[5] / h[4] : 0.0, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
+            h[6] ? (double)h[12] / h[6] : 0.0, h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves,
+            (double)h[8] / (double)nblocks, (double)h[9] / (double)nblocks);
   }
   return RDOOM_OK;
 }

@@ -42,8 +42,6 @@ struct rdoom_batch {
   uint32_t *d_entries = nullptr;   // per pose: entry_cap tile-list entries (record index | quadrant mask << 28)
   uint32_t *d_overflow = nullptr;  // per pose: 1 = bins incomplete, rasteriser scans the sorted list
   uint32_t entry_cap = 0, n_tiles = 0;
-  uint32_t *d_repair_count = nullptr;  // tiles that deferred entries to the rasteriser's repair kernel
-  void *d_repair_store = nullptr;      // their items and (quadrant, record) pair lists
   uint32_t *d_fix_count = nullptr;  // [0] = queued pixels, [1] = error flag (fixup list overflow)
   uint2 *d_fix_list = nullptr;
   uint32_t fix_cap = 1u << 20;
@@ -262,7 +260,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
 void rdoom_batch_destroy(rdoom_batch *b) {
   if (!b) return;
   for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_tmp_recs, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries,
-                  (void *)b->d_overflow, (void *)b->d_repair_count, b->d_repair_store, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
+                  (void *)b->d_overflow, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb})
     if (p) (void)hipFree(p);
   for (auto &e : b->ev)
@@ -301,8 +299,6 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_tile_hdr, sizeof(uint2) * (size_t)b->n_tiles * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_entries, sizeof(uint32_t) * (size_t)b->entry_cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_overflow, sizeof(uint32_t) * max_poses);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_repair_count, sizeof(uint32_t));
-  if (e == hipSuccess) e = hipMalloc(&b->d_repair_store, raster_repair_bytes(max_poses, b->n_tiles));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_count, 2 * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_list, sizeof(uint2) * (size_t)b->fix_cap);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
@@ -392,8 +388,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   if (tm) HIP_TRY(hipEventRecord(b->ev[1], st));
   uint32_t *prim_out = b->want_prim ? b->d_prim : nullptr;
   if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, W, H, tiles_x, tiles_y,
-                                      b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out,
-                                      b->d_repair_count, b->d_repair_store, b->max_poses))
+                                      b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out))
     return rs;
   if (tm) HIP_TRY(hipEventRecord(b->ev[2], st));
   if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, b->d_poses, W, H, tiles_x,

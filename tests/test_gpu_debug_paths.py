@@ -7,8 +7,6 @@ process sets its own, they are process-wide).  Every hook selects an equivalent 
   frag_nq=1      one quad per lane in the fragment kernel (default two when the width is a multiple of 8);
   vis32=1        32-bit visibility words (levels with >= 65535 triangles) instead of 16-bit ones;
   no_cover=1     the rasteriser without its depth-only body for quadrant-covering triangles;
-  defer_all=1    the rasteriser defers every entry: raster_repair_kernel resolves the whole frame with the general body;
-  defer_cap=n    deferred pairs a tile may list before its whole list is replayed by the repair kernel;
   frag_bw=k      the fragment kernel's wave block is 2^k units wide (default 3: 64 x 8 pixels)."""
 import os
 import re
@@ -53,8 +51,6 @@ def test_32_bit_visibility_words():
     assert bad == 0
     bad, fixups = run_child({'vis32': 1, 'leak_mod': 101})
     assert bad == 0 and fixups > 3000
-    bad, _ = run_child({'vis32': 1, 'defer_all': 1})
-    assert bad == 0
 
 
 def test_one_quad_per_lane_fragment_kernel():
@@ -67,23 +63,6 @@ def test_rasteriser_without_the_quadrant_cover_body():
     bad, _ = run_child({'no_cover': 1})
     assert bad == 0
     bad, _ = run_child({'no_cover': 1, 'no_bins': 1})
-    assert bad == 0
-
-
-def test_repair_kernel_resolves_everything_when_all_entries_are_deferred():
-    """defer_all=1: the hot rasteriser applies nothing; every (quadrant, record) pair goes through raster_repair_kernel's
-    general body -- tiles with more than 64 pairs through the whole-list replay"""
-    bad, _ = run_child({'defer_all': 1})
-    assert bad == 0
-    bad, _ = run_child({'defer_all': 1, 'no_bins': 1})
-    assert bad == 0
-
-
-@pytest.mark.parametrize('cap', [1, 3])
-def test_deferred_pair_list_overflow_replays_the_tile_list(cap):
-    bad, _ = run_child({'defer_cap': cap})
-    assert bad == 0
-    bad, _ = run_child({'defer_cap': cap, 'entry_cap': 300})
     assert bad == 0
 
 
