@@ -20,14 +20,16 @@ namespace {
 
 // =================================================================================================
 // Kernel 1: vertex stage + triangle setup (V2..V5, S1..S6) and front-to-back ordering.
-// One 256-thread workgroup per pose walks the level's triangle list in chunks; visible triangles are
-// compacted in order (ballot + prefix) into the pose's record array, then a counting sort over a
-// log-depth bucket (exponent + top mantissa bits of the nearest vertex's w) produces the `sorted`
-// list the rasteriser consumes: near geometry first, so its exact early-z test rejects most occluded
-// triangles.  The order only affects speed: the winner is the lexicographic min of (d24, primitive).
+// One 256-thread workgroup per pose walks the level's triangle list in chunks of 1024, in two phases per chunk: every
+// thread culls four triangles (the cheap half of the set-up: transform, S1, S4, S6), the survivors are compacted in
+// order, and then one lane per SURVIVOR does the full set-up -- all lanes busy, where a single pass would run the whole
+// set-up for every wave that holds one visible triangle.  A counting sort over a log-depth bucket (exponent + top
+// mantissa bits of the nearest vertex's w; the bucket travels in the record) then produces the `sorted` list the
+// rasteriser consumes: near geometry first, so its exact early-z test rejects most occluded triangles.  The order only
+// affects speed: the winner is the lexicographic min of (d24, primitive).
 // =================================================================================================
 constexpr uint32_t SORT_BUCKETS = 2048;
-constexpr uint32_t SORT_KEY_CAP = 8192;  // visible triangles per pose whose keys fit the LDS key array (more: unsorted, still correct)
+constexpr uint32_t CULL_CHUNK = 1024;  // triangles culled per outer iteration (four per thread), survivors set up densely
 
 __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const PoseConst &pc,
                                                const ObjectConst *__restrict__ objs, uint32_t t, int width,
@@ -199,50 +201,73 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
                                                     uint4 *__restrict__ sorted, uint32_t *__restrict__ counts,
                                                     uint32_t cap) {
   __shared__ uint32_t hist[SORT_BUCKETS];
-  __shared__ uint16_t keys[SORT_KEY_CAP];
-  __shared__ uint32_t wcnt[4];
+  __shared__ uint32_t cand[CULL_CHUNK];  // this chunk's visible triangles, ascending
+  __shared__ uint32_t wsum[4];
   __shared__ uint32_t scan_tmp[256];
   const uint32_t pose = blockIdx.x;
   const PoseConst &pc = poses[pose];
+  const ObjectConst *objs = objects ? objects + (size_t)pose * n_objects : nullptr;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   TriRec *prec = recs + (size_t)pose * cap;
-  TriRec *ptmp = tmp_recs + (size_t)pose * cap;  // records in compaction (= primitive) order, before the sort
+  TriRec *ptmp = tmp_recs + (size_t)pose * cap;  // records in primitive order, before the sort
   uint4 *psorted = sorted + (size_t)pose * cap;
   for (uint32_t i = tid; i < SORT_BUCKETS; i += 256) hist[i] = 0;
   __syncthreads();
   uint32_t n = 0;  // visible so far (uniform)
-  for (uint32_t base = 0; base < lv.ntri; base += 256u) {
-    const uint32_t t = base + (uint32_t)tid;
-    RasterRec rr;
-    ShadeRec sr;
-    float wkey;
-    const bool ok = t < lv.ntri && setup_triangle(lv, pc, objects ? objects + (size_t)pose * n_objects : nullptr, t,
-                                                  width, height, kinds_mask, rr, sr, wkey);
-    const unsigned long long m = __ballot(ok);
-    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+  for (uint32_t base = 0; base < lv.ntri; base += CULL_CHUNK) {
+    // Phase 1, cull: four consecutive triangles per thread.  Only setup_triangle()'s verdict and nothing it writes is
+    // used, so the compiler drops the planes, divisions and texture parameters from this instantiation; the culls
+    // themselves (kind mask, S1, S4, S6) are the same operations as in phase 2.
+    uint32_t vis4 = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) {
+      const uint32_t t = base + (uint32_t)tid * 4u + j;
+      RasterRec rr;
+      ShadeRec sr;
+      float wkey;
+      if (t < lv.ntri && setup_triangle(lv, pc, objs, t, width, height, kinds_mask, rr, sr, wkey)) vis4 |= 1u << j;
+    }
+    // ordered compaction of the survivors: exclusive scan of the per-thread counts over the workgroup
+    const uint32_t mine = (uint32_t)__popc(vis4);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    uint32_t off = n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), total = 0;
+    uint32_t off = incl - mine, total = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-      const uint32_t c = wcnt[w];
+      const uint32_t c = wsum[w];
       if (w < wave) off += c;
       total += c;
     }
-    if (ok) {
-      ptmp[off].r = rr;
-      ptmp[off].s = sr;
-      const uint32_t bucket = depth_bucket(wkey);
-      if (off < SORT_KEY_CAP) {
-        keys[off] = (uint16_t)bucket;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++)
+      if ((vis4 >> j) & 1u) cand[off++] = base + (uint32_t)tid * 4u + j;
+    __syncthreads();
+    // Phase 2, set-up: one lane per visible triangle, all lanes busy; record k of the pose is the k-th visible triangle
+    for (uint32_t s0 = 0; s0 < total; s0 += 256u) {
+      const uint32_t sidx = s0 + (uint32_t)tid;
+      if (sidx < total) {
+        RasterRec rr;
+        ShadeRec sr;
+        float wkey;
+        (void)setup_triangle(lv, pc, objs, cand[sidx], width, height, kinds_mask, rr, sr, wkey);
+        const uint32_t bucket = depth_bucket(wkey);
+        rr.pad[0] = bucket;  // travels with the record to the sort below
+        ptmp[n + sidx].r = rr;
+        ptmp[n + sidx].s = sr;
         atomicAdd(&hist[bucket], 1u);
       }
     }
     n += total;
-    __syncthreads();
+    __syncthreads();  // cand and wsum are rewritten by the next chunk
   }
   if (tid == 0) counts[pose] = n;
-  const bool sortable = n <= SORT_KEY_CAP;  // else too many for the LDS key array: primitive order (still correct)
-  if (sortable) {
+  {
     // exclusive scan of the histogram: 8 buckets per thread + a 256-wide block scan
     uint32_t local[8], sum = 0;
 #pragma unroll
@@ -266,15 +291,16 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
   // move every record to its near-to-far position: record index == position in the sorted list from here on
   // (bin/raster/fragment gather records by that index; ptmp was written by this workgroup, same CU, after a barrier)
   for (uint32_t i = tid; i < n; i += 256) {
-    const uint32_t bucket = sortable ? (uint32_t)keys[i] : 0u;
-    const uint32_t pos = sortable ? atomicAdd(&hist[bucket], 1u) : i;
     const uint4 *src = reinterpret_cast<const uint4 *>(&ptmp[i]);
-    uint4 *dst = reinterpret_cast<uint4 *>(&prec[pos]);
+    uint4 *dst = reinterpret_cast<uint4 *>(&prec[0]);
     uint4 v[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) v[k] = src[k];
+    const uint32_t bucket = v[4].z;  // RasterRec::pad[0] (dword 18)
+    const uint32_t pos = atomicAdd(&hist[bucket], 1u);
+    v[4].z = 0u;
 #pragma unroll
-    for (int k = 0; k < 9; k++) dst[k] = v[k];
+    for (int k = 0; k < 9; k++) dst[(size_t)pos * 9 + k] = v[k];
     psorted[pos] = make_uint4(v[3].w, v[4].x, pos, bucket);  // RasterRec::bb0, bb1 (dwords 15, 16)
   }
 }
