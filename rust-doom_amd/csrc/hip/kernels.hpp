@@ -16,9 +16,10 @@ namespace rdoom_dev {
 constexpr uint32_t MAX_TILES = 8192;     // tiles per frame the binning kernel keeps counters for
 
 // Kernel 1: vertex stage, triangle setup, near-to-far record order (setup.hip)
-void launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
-                  const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
-                  TriRec *recs, TriRec *tmp_recs, uint4 *sorted, uint32_t *counts, uint32_t cap);
+rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
+                          const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
+                          TriRec *recs, uint32_t *visible, uint4 *sorted, uint32_t *counts, uint32_t *ghist, uint32_t cap);
+size_t setup_histogram_bytes(uint32_t max_poses);  // scratch of the counting sort (per pose: one counter per depth bucket)
 // Kernel 1b: per-tile triangle lists (bin.hip).  false = the frame has too many tiles for the kernel's LDS counters:
 // nothing was launched and the caller must flag every pose as "bins incomplete"
 bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,

@@ -81,9 +81,21 @@ struct alignas(16) TriRec {  // 144 bytes = 9 x 16 B: what one (pose, visible tr
 };
 static_assert(sizeof(TriRec) == 144, "TriRec layout");
 
+// Up to 32 consecutive triangles of one object with the bounding box of their vertices: the set-up kernel discards a
+// whole cluster when the box proves that every triangle in it fails S1 or S6 (corner arguments on the same fmaf chains).
+constexpr uint32_t CLUSTER_TRIS = 32;
+struct alignas(16) Cluster {  // 32 bytes
+  float lo[3], hi[3];
+  uint32_t first;         // first triangle
+  uint32_t count_object;  // count | object id << 8 | never-cull << 31 (decor: sprite.vert moves the vertices per pose)
+};
+static_assert(sizeof(Cluster) == 32, "Cluster layout");
+
 struct DeviceLevelView {
   const LevelTri *tris;
   uint32_t ntri;
+  const Cluster *clusters;
+  uint32_t n_clusters;
   // one u16 texel store: the wall atlas (lo = palette index, bit 15 = transparent) followed, at element
   // flat_base (a multiple of 1024), by the flat atlas promoted to u16 (hi byte 0: never transparent)
   const uint16_t *texels;

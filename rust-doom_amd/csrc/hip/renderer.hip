@@ -27,6 +27,7 @@ bool is_pow2(uint32_t x) { return x != 0 && (x & (x - 1)) == 0; }
 struct rdoom_level {
   int device = 0;
   DeviceLevelView view{};
+  void *d_clusters = nullptr;
   void *d_tris = nullptr, *d_flat = nullptr, *d_wall = nullptr, *d_sky = nullptr, *d_cmap = nullptr;
   uint32_t ntri = 0, n_objects = 1;
 };
@@ -36,7 +37,7 @@ struct rdoom_batch {
   uint32_t width = 0, height = 0, max_poses = 0, cap = 0, last_n = 0;
   PoseConst *d_poses = nullptr;
   TriRec *d_recs = nullptr;   // max_poses x cap records in near-to-far order (setup -> bin, raster, fragment)
-  TriRec *d_tmp_recs = nullptr;  // same size: setup's compaction-order staging
+  uint32_t *d_visible = nullptr;  // max_poses x cap: the visible triangles of each pose (cull kernel -> set-up kernel)
   uint4 *d_sorted = nullptr;  // per pose: (bbox, record index, depth bucket) near-to-far (coarse test input)
   uint2 *d_tile_hdr = nullptr;     // per (pose, tile): (first entry, entry count)
   uint32_t *d_entries = nullptr;   // per pose: entry_cap tile-list entries (record index | quadrant mask << 28)
@@ -46,6 +47,7 @@ struct rdoom_batch {
   uint2 *d_fix_list = nullptr;
   uint32_t fix_cap = 1u << 20;
   uint32_t *d_counts = nullptr, *d_vis = nullptr, *d_prim = nullptr;
+  uint32_t *d_ghist = nullptr;  // counting sort of the set-up: per pose, one counter per depth bucket
   uint8_t *d_fb = nullptr;
   PoseConst *h_poses = nullptr;  // pinned staging for the per-pose constants
   ObjectConst *d_objects = nullptr, *h_objects = nullptr;  // max_poses x n_objects, allocated on first use
@@ -73,7 +75,7 @@ rdoom_status rdoom_set_device(int32_t device) {
 
 void rdoom_level_destroy(rdoom_level *level) {
   if (!level) return;
-  for (void *p : {level->d_tris, level->d_flat, level->d_wall, level->d_sky, level->d_cmap})
+  for (void *p : {level->d_clusters, level->d_tris, level->d_flat, level->d_wall, level->d_sky, level->d_cmap})
     if (p) (void)hipFree(p);
   delete level;
 }
@@ -214,7 +216,29 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
     if (e != hipSuccess) return e;
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
   };
+  // clusters for the set-up kernel's coarse cull: runs of at most CLUSTER_TRIS consecutive triangles of one object
+  std::vector<Cluster> clusters;
+  for (size_t t = 0; t < tris.size();) {
+    const uint32_t obj = tris[t].packed >> 20;
+    const bool decor = ((tris[t].packed >> 16) & 3u) == RDOOM_KIND_DECOR;
+    Cluster c;
+    for (int k = 0; k < 3; k++) c.lo[k] = INFINITY, c.hi[k] = -INFINITY;
+    c.first = (uint32_t)t;
+    uint32_t n = 0;
+    while (t < tris.size() && n < CLUSTER_TRIS && (tris[t].packed >> 20) == obj &&
+           (((tris[t].packed >> 16) & 3u) == RDOOM_KIND_DECOR) == decor) {
+      for (int v = 0; v < 3; v++)
+        for (int k = 0; k < 3; k++) {
+          c.lo[k] = std::min(c.lo[k], tris[t].pos[3 * v + k]);
+          c.hi[k] = std::max(c.hi[k], tris[t].pos[3 * v + k]);
+        }
+      t++, n++;
+    }
+    c.count_object = n | (obj << 8) | (decor ? 0x80000000u : 0u);
+    clusters.push_back(c);
+  }
   hipError_t e = upload(&lv->d_tris, tris.data(), tris.size() * sizeof(LevelTri));
+  if (e == hipSuccess) e = upload(&lv->d_clusters, clusters.data(), clusters.size() * sizeof(Cluster));
   // unified u16 texel store: wall atlas, then (at a multiple of 1024 elements) the flat atlas promoted to u16
   const size_t wall_n = d->wall_atlas ? (size_t)d->wall_w * d->wall_h : 0;
   const size_t flat_n = d->flat_atlas ? (size_t)d->flat_w * d->flat_h : 0;
@@ -239,6 +263,8 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
   }
   lv->view.tris = (const LevelTri *)lv->d_tris;
   lv->view.ntri = lv->ntri;
+  lv->view.clusters = (const Cluster *)lv->d_clusters;
+  lv->view.n_clusters = (uint32_t)clusters.size();
   lv->view.texels = (const uint16_t *)lv->d_wall;
   lv->view.flat_base = (uint32_t)flat_base;
   lv->view.decor_base = (uint32_t)decor_base;
@@ -259,8 +285,8 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
 
 void rdoom_batch_destroy(rdoom_batch *b) {
   if (!b) return;
-  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_tmp_recs, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries,
-                  (void *)b->d_overflow, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
+  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_visible, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries,
+                  (void *)b->d_overflow, (void *)b->d_ghist, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb})
     if (p) (void)hipFree(p);
   for (auto &e : b->ev)
@@ -291,7 +317,7 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   const size_t npx = (size_t)width * height * max_poses;
   hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_tmp_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_visible, sizeof(uint32_t) * (size_t)b->cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_sorted, sizeof(uint4) * (size_t)b->cap * max_poses);
   b->n_tiles = ((width + TILE_W - 1) / TILE_W) * ((height + TILE_H - 1) / TILE_H);
   b->entry_cap = std::max<uint32_t>(65536u, 32u * b->n_tiles);  // tile-list entries per pose; beyond it the pose is scanned
@@ -302,6 +328,7 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_count, 2 * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_list, sizeof(uint2) * (size_t)b->fix_cap);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_ghist, setup_histogram_bytes(max_poses));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, (b->vis16 ? sizeof(uint16_t) : sizeof(uint32_t)) * npx);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
   if (e == hipSuccess) {  // sky.frag:13's ndc per column / row, same two operations as the per-pixel form
@@ -376,8 +403,10 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   HIP_TRY(hipEventRecord(b->ev_copy, st));
   const int W = (int)b->width, H = (int)b->height;
   if (lv->ntri)
-    launch_setup(st, n, lv->view, b->d_poses, object_modelviews ? (const ObjectConst *)b->d_objects : nullptr, lv->n_objects,
-                 W, H, kinds_mask, b->d_recs, b->d_tmp_recs, b->d_sorted, b->d_counts, b->cap);
+    if (rdoom_status rs = launch_setup(st, n, lv->view, b->d_poses, object_modelviews ? (const ObjectConst *)b->d_objects : nullptr,
+                                       lv->n_objects, W, H, kinds_mask, b->d_recs, b->d_visible, b->d_sorted, b->d_counts,
+                                       b->d_ghist, b->cap))
+      return rs;
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   if (!(lv->ntri && !rdoom::debug_options().no_bins &&
         launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,

@@ -20,25 +20,59 @@ namespace {
 
 // =================================================================================================
 // Kernel 1: vertex stage + triangle setup (V2..V5, S1..S6) and front-to-back ordering.
-// One 256-thread workgroup per pose walks the level's triangle list in chunks of 1024, in two phases per chunk: every
-// thread culls four triangles (the cheap half of the set-up: transform, S1, S4, S6), the survivors are compacted in
-// order, and then one lane per SURVIVOR does the full set-up -- all lanes busy, where a single pass would run the whole
-// set-up for every wave that holds one visible triangle.  A counting sort over a log-depth bucket (exponent + top
-// mantissa bits of the nearest vertex's w; the bucket travels in the record) then produces the `sorted` list the
-// rasteriser consumes: near geometry first, so its exact early-z test rejects most occluded triangles.  The order only
-// affects speed: the winner is the lexicographic min of (d24, primitive).
+// Three launches, records written once:
+//   cull_kernel       a few workgroups per pose, each with a share of the level's clusters (runs of <= 32 triangles with a
+//                     bounding box): coarse cull of whole clusters, then the cheap half of the set-up (transform, S1, S4,
+//                     S6) for four triangles per thread; the visible triangles are listed and their log-depth buckets
+//                     (exponent + top mantissa bits of the nearest vertex's w) counted;
+//   sort_scan_kernel  exclusive scan of each pose's bucket histogram;
+//   setup_kernel      one lane per VISIBLE triangle does the full set-up -- all lanes busy, where a single pass would run
+//                     the whole set-up for every wave that holds one visible triangle -- and stores the record at its
+//                     near-to-far position.
+// Near geometry first lets the rasteriser's exact early-z test reject most occluded triangles.  The order only affects
+// speed: the winner is the lexicographic min of (d24, primitive).
 // =================================================================================================
 constexpr uint32_t SORT_BUCKETS = 2048;
-constexpr uint32_t CULL_CHUNK = 1024;  // triangles culled per outer iteration (four per thread), survivors set up densely
+constexpr uint32_t CULL_CHUNK = 1024;  // triangle slots culled per outer iteration (four per thread), survivors set up densely
+constexpr uint32_t CLUSTER_LIST = 4096;  // clusters whose survivors fit the LDS list (larger levels: no coarse cull)
+
+// Coarse cull of a cluster (exact implications, no new rule): true only if EVERY triangle whose vertices lie in the box
+// fails S1 or S6.  A clip coordinate is one fmaf chain over (x, y, z), monotone in each of them, so its extremes over the
+// box sit at corners chosen by the signs of the coefficients; rounding, multiplication by a positive constant and IEEE
+// division are monotone, so the bounds survive S2 and S6's own operations:
+//   S1  every vertex has w <= max w <= 0;
+//   S6  needs min w >= 1e-5 (its bounding-box branch), then e.g. left of the frame: every vertex has
+//       sx = ((X + W) * hw) / w <= ((Xmax + Wmax) * hw) / Wmax < -2, hence ceil(max sx) + 1 < 0.
+__device__ __forceinline__ bool cluster_culled(const Cluster &c, const float *pm, int width, int height) {
+  auto ext = [&](int r, bool want_max) {
+    const float a = pm[r], b = pm[4 + r], cc = pm[8 + r];
+    const float x = ((a > 0.0f) == want_max) ? c.hi[0] : c.lo[0];
+    const float y = ((b > 0.0f) == want_max) ? c.hi[1] : c.lo[1];
+    const float z = ((cc > 0.0f) == want_max) ? c.hi[2] : c.lo[2];
+    return fmaf(cc, z, fmaf(b, y, fmaf(a, x, pm[12 + r])));
+  };
+  const float wmax = ext(3, true);
+  if (wmax <= 0.0f) return true;  // S1
+  const float wmin = ext(3, false);
+  if (!(wmin >= 1e-5f)) return false;
+  const float hw = 0.5f * (float)width, hh = 0.5f * (float)height;
+  const float xhi = ((ext(0, true) + wmax) * hw), xlo = ((ext(0, false) + wmin) * hw);
+  const float yhi = ((ext(1, true) + wmax) * hh), ylo = ((ext(1, false) + wmin) * hh);
+  // a negative numerator divided by the LARGEST w is the quotient closest to zero; likewise a positive one
+  const bool left = xhi < 0.0f && xhi / wmax < -2.0f;
+  const bool right = xlo > 0.0f && xlo / wmax >= (float)width + 1.0f;
+  const bool below = yhi < 0.0f && yhi / wmax < -2.0f;
+  const bool above = ylo > 0.0f && ylo / wmax >= (float)height + 1.0f;
+  return left | right | below | above;
+}
 
 __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const PoseConst &pc,
-                                               const ObjectConst *__restrict__ objs, uint32_t t, int width,
-                                               int height, uint32_t kinds_mask, RasterRec &rr, ShadeRec &sr,
+                                               const ObjectConst *__restrict__ objs, uint32_t t, const LevelTri &tri,
+                                               int width, int height, uint32_t kinds_mask, RasterRec &rr, ShadeRec &sr,
                                                float &wkey) {
   wkey = 0.0f;
-  bool ok = t < lv.ntri;
-  if (ok) {
-    const LevelTri tri = lv.tris[t];
+  bool ok = true;
+  {
     const uint32_t kind = (tri.packed >> 16) & 3u;
     ok = ((kinds_mask >> kind) & 1u) != 0u;
     if (ok) {
@@ -194,40 +228,98 @@ __device__ __forceinline__ uint32_t depth_bucket(float wmin) {
   return min(b, SORT_BUCKETS - 1u);
 }
 
-__global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
-                                                    const ObjectConst *__restrict__ objects, uint32_t n_objects,
-                                                    int width, int height, uint32_t kinds_mask,
-                                                    TriRec *__restrict__ recs, TriRec *__restrict__ tmp_recs,
-                                                    uint4 *__restrict__ sorted, uint32_t *__restrict__ counts,
-                                                    uint32_t cap) {
-  __shared__ uint32_t hist[SORT_BUCKETS];
-  __shared__ uint32_t cand[CULL_CHUNK];  // this chunk's visible triangles, ascending
+__global__ __launch_bounds__(256) void cull_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
+                                                   const ObjectConst *__restrict__ objects, uint32_t n_objects,
+                                                   int width, int height, uint32_t kinds_mask,
+                                                   uint32_t *__restrict__ visible, uint32_t *__restrict__ counts,
+                                                   uint32_t *__restrict__ ghist, uint32_t cap, uint32_t groups) {
+  __shared__ uint32_t hist[SORT_BUCKETS];   // this workgroup's share of the pose's depth-bucket histogram
+  __shared__ uint32_t cand[CULL_CHUNK];     // this chunk's visible triangles
+  __shared__ uint16_t clist[CLUSTER_LIST];  // my clusters that survived the coarse cull, ascending
   __shared__ uint32_t wsum[4];
-  __shared__ uint32_t scan_tmp[256];
-  const uint32_t pose = blockIdx.x;
+  __shared__ uint32_t chunk_first;          // where this chunk's records go in the pose's staging array
+  __shared__ uint4 wstage[4][384];  // per wave: 2 x 32 level triangles (6 x 16 B each)
+  const uint32_t pose = blockIdx.y, group = blockIdx.x;
   const PoseConst &pc = poses[pose];
   const ObjectConst *objs = objects ? objects + (size_t)pose * n_objects : nullptr;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  TriRec *prec = recs + (size_t)pose * cap;
-  TriRec *ptmp = tmp_recs + (size_t)pose * cap;  // records in primitive order, before the sort
-  uint4 *psorted = sorted + (size_t)pose * cap;
+  uint32_t *pvisible = visible + (size_t)pose * cap;  // the pose's visible triangles, in arrival order
+  uint32_t *phist = ghist + (size_t)pose * SORT_BUCKETS;
   for (uint32_t i = tid; i < SORT_BUCKETS; i += 256) hist[i] = 0;
+  // my share of the level's clusters
+  const uint32_t c_begin = (uint32_t)(((uint64_t)lv.n_clusters * group) / groups),
+                 c_end = (uint32_t)(((uint64_t)lv.n_clusters * (group + 1u)) / groups);
+  // Phase 0, coarse cull: one lane per cluster, survivors listed in order
+  const bool listed = c_end - c_begin <= CLUSTER_LIST;
+  uint32_t n_live = c_end - c_begin;  // uniform
+  if (listed) {
+    n_live = 0;
+    for (uint32_t c0 = c_begin; c0 < c_end; c0 += 256u) {
+      const uint32_t ci = c0 + (uint32_t)tid;
+      bool live = false;
+      if (ci < c_end) {
+        const Cluster c = lv.clusters[ci];
+        const float *pm = objs ? objs[(c.count_object >> 8) & 0xFFFu].pm : pc.pm;
+        live = (c.count_object >> 31) != 0u || !cluster_culled(c, pm, width, height);
+      }
+      const unsigned long long m = __ballot(live);
+      if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+      __syncthreads();
+      uint32_t off = n_live + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const uint32_t cnt = wsum[w];
+        if (w < wave) off += cnt;
+        total += cnt;
+      }
+      if (live) clist[off] = (uint16_t)(ci - c_begin);
+      n_live += total;
+      __syncthreads();
+    }
+  }
   __syncthreads();
-  uint32_t n = 0;  // visible so far (uniform)
-  for (uint32_t base = 0; base < lv.ntri; base += CULL_CHUNK) {
-    // Phase 1, cull: four consecutive triangles per thread.  Only setup_triangle()'s verdict and nothing it writes is
-    // used, so the compiler drops the planes, divisions and texture parameters from this instantiation; the culls
-    // themselves (kind mask, S1, S4, S6) are the same operations as in phase 2.
-    uint32_t vis4 = 0;
+  const uint32_t n_slots = n_live * CLUSTER_TRIS;  // every live cluster owns CLUSTER_TRIS triangle slots
+  uint4 *stage = wstage[wave];
+  for (uint32_t base = 0; base < n_slots; base += CULL_CHUNK) {
+    // Phase 1, cull: four steps of one triangle per lane.  In a step the two halves of a wave take the 32 slots of two
+    // clusters: the 3 KiB of a cluster's triangles are read with whole-line loads into the wave's LDS stage (a lane
+    // reading its own 96 bytes at a 96-byte stride would touch a line per lane and load), and each lane picks its
+    // triangle up from there.  Only setup_triangle()'s verdict and nothing it writes is used here, so the compiler drops
+    // the planes, divisions and texture parameters from this instantiation; the culls themselves (kind mask, S1, S4, S6)
+    // are the same operations as in phase 2.
+    uint32_t vis4 = 0, tri_of[4], bucket_of[4];
 #pragma unroll
     for (uint32_t j = 0; j < 4u; j++) {
-      const uint32_t t = base + (uint32_t)tid * 4u + j;
-      RasterRec rr;
-      ShadeRec sr;
-      float wkey;
-      if (t < lv.ntri && setup_triangle(lv, pc, objs, t, width, height, kinds_mask, rr, sr, wkey)) vis4 |= 1u << j;
+      const uint32_t slot = base + j * 256u + (uint32_t)tid;  // lane-contiguous
+      const uint32_t half = (uint32_t)lane >> 5, in = (uint32_t)lane & 31u;
+      uint32_t first = 0, count = 0;
+      if (slot < n_slots) {
+        const uint32_t ci = c_begin + (listed ? (uint32_t)clist[slot / CLUSTER_TRIS] : slot / CLUSTER_TRIS);
+        first = lv.clusters[ci].first, count = lv.clusters[ci].count_object & 0xFFu;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the stage's previous readers are done
+      const uint4 *src = reinterpret_cast<const uint4 *>(lv.tris + first);
+#pragma unroll
+      for (uint32_t k = 0; k < 6u; k++) {  // 6 x 32 x 16 bytes per half-wave: the cluster's triangles, line by line
+        const uint32_t idx = k * 32u + in;
+        if (idx < count * 6u) stage[half * 192u + idx] = src[idx];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      tri_of[j] = first + in;
+      if (in < count) {
+        LevelTri tri;
+        uint4 *dst = reinterpret_cast<uint4 *>(&tri);
+#pragma unroll
+        for (uint32_t k = 0; k < 6u; k++) dst[k] = stage[half * 192u + in * 6u + k];
+        RasterRec rr;
+        ShadeRec sr;
+        float wkey;
+        if (setup_triangle(lv, pc, objs, tri_of[j], tri, width, height, kinds_mask, rr, sr, wkey)) vis4 |= 1u << j;
+        bucket_of[j] = depth_bucket(wkey);
+      }
     }
-    // ordered compaction of the survivors: exclusive scan of the per-thread counts over the workgroup
+    // compaction of the survivors (any order will do: the sort below re-orders, and nothing depends on record order):
+    // exclusive scan of the per-thread counts over the workgroup
     const uint32_t mine = (uint32_t)__popc(vis4);
     uint32_t incl = mine;
 #pragma unroll
@@ -246,72 +338,117 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
     }
 #pragma unroll
     for (uint32_t j = 0; j < 4u; j++)
-      if ((vis4 >> j) & 1u) cand[off++] = base + (uint32_t)tid * 4u + j;
-    __syncthreads();
-    // Phase 2, set-up: one lane per visible triangle, all lanes busy; record k of the pose is the k-th visible triangle
-    for (uint32_t s0 = 0; s0 < total; s0 += 256u) {
-      const uint32_t sidx = s0 + (uint32_t)tid;
-      if (sidx < total) {
-        RasterRec rr;
-        ShadeRec sr;
-        float wkey;
-        (void)setup_triangle(lv, pc, objs, cand[sidx], width, height, kinds_mask, rr, sr, wkey);
-        const uint32_t bucket = depth_bucket(wkey);
-        rr.pad[0] = bucket;  // travels with the record to the sort below
-        ptmp[n + sidx].r = rr;
-        ptmp[n + sidx].s = sr;
-        atomicAdd(&hist[bucket], 1u);
+      if ((vis4 >> j) & 1u) {
+        cand[off++] = tri_of[j];
+        atomicAdd(&hist[bucket_of[j]], 1u);
       }
-    }
-    n += total;
-    __syncthreads();  // cand and wsum are rewritten by the next chunk
-  }
-  if (tid == 0) counts[pose] = n;
-  {
-    // exclusive scan of the histogram: 8 buckets per thread + a 256-wide block scan
-    uint32_t local[8], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      local[k] = sum;
-      sum += hist[tid * 8 + k];
-    }
-    scan_tmp[tid] = sum;
+    if (tid == 0) chunk_first = total ? atomicAdd(&counts[pose], total) : 0u;  // the pose's workgroups share one list
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-      const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
-      __syncthreads();
-      scan_tmp[tid] += v;
-      __syncthreads();
-    }
-    const uint32_t before = scan_tmp[tid] - sum;
+    for (uint32_t i = tid; i < total; i += 256u) pvisible[chunk_first + i] = cand[i];
+    __syncthreads();  // cand, wsum and chunk_first are rewritten by the next chunk
+  }
+  for (uint32_t i = tid; i < SORT_BUCKETS; i += 256) {
+    const uint32_t c = hist[i];
+    if (c) atomicAdd(&phist[i], c);
+  }
+}
+
+// Counting sort, second step: exclusive scan of the pose's bucket histogram, in place (one workgroup per pose).
+__global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ ghist) {
+  __shared__ uint32_t scan_tmp[256];
+  uint32_t *phist = ghist + (size_t)blockIdx.x * SORT_BUCKETS;
+  const int tid = threadIdx.x;
+  uint32_t local[8], sum = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) hist[tid * 8 + k] = before + local[k];
+  for (int k = 0; k < 8; k++) {
+    local[k] = sum;
+    sum += phist[tid * 8 + k];
+  }
+  scan_tmp[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
+    __syncthreads();
+    scan_tmp[tid] += v;
     __syncthreads();
   }
-  // move every record to its near-to-far position: record index == position in the sorted list from here on
-  // (bin/raster/fragment gather records by that index; ptmp was written by this workgroup, same CU, after a barrier)
-  for (uint32_t i = tid; i < n; i += 256) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(&ptmp[i]);
-    uint4 *dst = reinterpret_cast<uint4 *>(&prec[0]);
-    uint4 v[9];
+  const uint32_t before = scan_tmp[tid] - sum;
 #pragma unroll
-    for (int k = 0; k < 9; k++) v[k] = src[k];
-    const uint32_t bucket = v[4].z;  // RasterRec::pad[0] (dword 18)
-    const uint32_t pos = atomicAdd(&hist[bucket], 1u);
-    v[4].z = 0u;
+  for (int k = 0; k < 8; k++) phist[tid * 8 + k] = before + local[k];
+}
+
+// Kernel 1c: full set-up (V2..V5, S1..S6), one lane per visible triangle, all lanes busy; the record goes straight to its
+// near-to-far position (scanned histogram + one atomic): record index == position in the sorted list from here on (bin /
+// raster / fragment gather records by that index).  The order inside a bucket is whatever the atomics hand out (nothing
+// depends on it).  A few workgroups per pose, each striding over the pose's list of visible triangles.
+__global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
+                                                    const ObjectConst *__restrict__ objects, uint32_t n_objects,
+                                                    int width, int height, uint32_t kinds_mask,
+                                                    const uint32_t *__restrict__ visible, TriRec *__restrict__ recs,
+                                                    uint4 *__restrict__ sorted, const uint32_t *__restrict__ counts,
+                                                    uint32_t *__restrict__ ghist, uint32_t cap) {
+  const uint32_t pose = blockIdx.y, n = counts[pose];
+  const PoseConst &pc = poses[pose];
+  const ObjectConst *objs = objects ? objects + (size_t)pose * n_objects : nullptr;
+  const uint32_t *pvisible = visible + (size_t)pose * cap;
+  TriRec *prec = recs + (size_t)pose * cap;
+  uint4 *psorted = sorted + (size_t)pose * cap;
+  uint32_t *phist = ghist + (size_t)pose * SORT_BUCKETS;
+  // positions: scanned histogram + rank.  The ranks of a chunk of 256 records are counted in LDS and each bucket that
+  // occurs claims its run with ONE global atomic (a returning global atomic per record serialises on the few buckets a
+  // pose's triangles crowd into)
+  __shared__ uint32_t lcount[SORT_BUCKETS], lbase[SORT_BUCKETS];
+  if (blockIdx.x * 256u >= n) return;  // uniform: nothing for this workgroup
+  for (uint32_t i = threadIdx.x; i < SORT_BUCKETS; i += 256u) lcount[i] = 0;
+  __syncthreads();
+  for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {  // uniform per workgroup
+    const uint32_t i = i0 + threadIdx.x;
+    const bool valid = i < n;
+    TriRec rec;
+    uint32_t bucket = 0, lrank = 0;
+    if (valid) {
+      const uint32_t t = pvisible[i];
+      const LevelTri tri = lv.tris[t];
+      float wkey;
+      (void)setup_triangle(lv, pc, objs, t, tri, width, height, kinds_mask, rec.r, rec.s, wkey);  // visible: the cull kernel said so
+      bucket = depth_bucket(wkey);
+      lrank = atomicAdd(&lcount[bucket], 1u);
+    }
+    __syncthreads();
+    if (valid && lrank == 0u) lbase[bucket] = atomicAdd(&phist[bucket], lcount[bucket]);
+    __syncthreads();
+    if (valid) {
+      const uint32_t pos = lbase[bucket] + lrank;
+      const uint4 *v = reinterpret_cast<const uint4 *>(&rec);
+      uint4 *dst = reinterpret_cast<uint4 *>(&prec[pos]);
 #pragma unroll
-    for (int k = 0; k < 9; k++) dst[(size_t)pos * 9 + k] = v[k];
-    psorted[pos] = make_uint4(v[3].w, v[4].x, pos, bucket);  // RasterRec::bb0, bb1 (dwords 15, 16)
+      for (uint32_t k = 0; k < 9u; k++) dst[k] = v[k];
+      psorted[pos] = make_uint4(rec.r.bb0, rec.r.bb1, pos, bucket);
+    }
+    __syncthreads();
+    if (valid && lrank == 0u) lcount[bucket] = 0u;  // ready for the next chunk (its atomics follow the barrier below)
+    __syncthreads();
   }
 }
 
 }  // namespace
 
-void launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
-                  const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
-                  TriRec *recs, TriRec *tmp_recs, uint4 *sorted, uint32_t *counts, uint32_t cap) {
-  hipLaunchKernelGGL(setup_kernel, dim3(n_poses), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,
-                     kinds_mask, recs, tmp_recs, sorted, counts, cap);
+rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
+                          const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
+                          TriRec *recs, uint32_t *visible, uint4 *sorted, uint32_t *counts, uint32_t *ghist, uint32_t cap) {
+  HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_poses, st));
+  HIP_TRY(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * SORT_BUCKETS * (size_t)n_poses, st));
+  // several workgroups per pose on large levels (each takes a share of the clusters): one would walk them serially
+  const uint32_t groups = std::min<uint32_t>(std::max<uint32_t>(lv.n_clusters / 96u, 1u), 16u);
+  hipLaunchKernelGGL(cull_kernel, dim3(groups, n_poses), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,
+                     kinds_mask, visible, counts, ghist, cap, groups);
+  hipLaunchKernelGGL(sort_scan_kernel, dim3(n_poses), dim3(256), 0, st, ghist);
+  const uint32_t place_groups = std::min<uint32_t>((cap + 1023u) / 1024u, 16u);  // about a fifth of a level is visible: one or two chunks of 256 records each
+  hipLaunchKernelGGL(setup_kernel, dim3(place_groups, n_poses), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,
+                     kinds_mask, visible, recs, sorted, counts, ghist, cap);
+  return RDOOM_OK;
 }
+
+size_t setup_histogram_bytes(uint32_t max_poses) { return sizeof(uint32_t) * SORT_BUCKETS * (size_t)max_poses; }
 
 }  // namespace rdoom_dev
