@@ -31,13 +31,37 @@ namespace {
 // rasteriser scans the sorted list instead.
 // =================================================================================================
 
+// Inclusive prefix sum over the workgroup: shuffles inside a wave, the wave totals through LDS (two barriers; tmp[w] ends
+// up holding the inclusive total of waves 0..w, so tmp[N / 64 - 1] is the grand total).  Ends with a barrier.
+template <int N>
+__device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *tmp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  __syncthreads();  // earlier readers of tmp are done
+  if (lane == 63) tmp[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int w = 0; w < N / 64; w++)
+    if (w < wave) before += tmp[w];
+  __syncthreads();
+  if (lane == 63) tmp[wave] = before + incl;
+  __syncthreads();
+  return before + incl;
+}
+
 template <int BIN_THREADS, int BIN_LOG2>  // threads per workgroup = triangles staged per round (one per thread)
 __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restrict__ recs,
                                                           const uint4 *__restrict__ sorted,
                                                           const uint32_t *__restrict__ counts, uint32_t cap,
                                                           int tiles_x, int tiles_y, uint2 *__restrict__ tile_hdr,
                                                           uint32_t *__restrict__ entries, uint32_t entry_cap,
-                                                          uint32_t *__restrict__ overflow) {
+                                                          uint2 *__restrict__ hits, uint32_t *__restrict__ overflow) {
   constexpr uint32_t BIN_CHUNK = BIN_THREADS;
   static_assert((1 << BIN_LOG2) == BIN_THREADS, "bin_kernel: BIN_LOG2");
   extern __shared__ uint32_t bin_dyn[];  // tile_cnt[T], tile_off[T]
@@ -46,6 +70,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restri
   __shared__ uint32_t trange[BIN_CHUNK];  // tile rectangle to visit: tx0 | ty0 << 8 | width << 16
   __shared__ uint32_t pref[BIN_CHUNK + 1];
   __shared__ uint32_t scan_tmp[BIN_THREADS];
+  __shared__ uint32_t n_hits;  // (triangle, tile) pairs that passed the tile test so far
   const uint32_t pose = blockIdx.x;
   const int tid = threadIdx.x;
   const uint32_t T = (uint32_t)(tiles_x * tiles_y);
@@ -58,9 +83,11 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restri
   const uint4 *psorted = sorted + (size_t)pose * cap;
   uint2 *hdr = tile_hdr + (size_t)pose * T;
   uint32_t *pent = entries + (size_t)pose * entry_cap;
+  uint2 *phits = hits + (size_t)pose * entry_cap;  // (entry, tile) of every pair that passed: the fill pass only scatters
   const uint32_t n = counts[pose];
   for (uint32_t i = tid; i < T; i += BIN_THREADS) tile_cnt[i] = 0;
-  for (int pass = 0; pass < 2; pass++) {
+  if (tid == 0) n_hits = 0;
+  {
     for (uint32_t cbase = 0; cbase < n; cbase += BIN_CHUNK) {
       const uint32_t cn = min(BIN_CHUNK, n - cbase);
       __syncthreads();  // previous round's readers of coef/pref are done (and tile_cnt / tile_off are ready)
@@ -89,16 +116,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restri
         nt = (tx1 >= tx0 && ty1 >= ty0) ? (uint32_t)((tx1 - tx0 + 1) * (ty1 - ty0 + 1)) : 0u;
         trange[tid] = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)(tx1 - tx0 + 1) << 16);  // tiles per side <= 128
       }
-      scan_tmp[tid] = nt;
-      __syncthreads();
-      for (int d = 1; d < BIN_THREADS; d <<= 1) {
-        const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
-        __syncthreads();
-        scan_tmp[tid] += v;
-        __syncthreads();
-      }
-      pref[tid] = scan_tmp[tid] - nt;  // exclusive; entries past cn repeat the total
-      const uint32_t W = scan_tmp[BIN_THREADS - 1];
+      const uint32_t incl = block_scan<BIN_THREADS>(nt, scan_tmp);  // inclusive prefix of nt over the workgroup
+      pref[tid] = incl - nt;                                        // exclusive; entries past cn repeat the total
+      const uint32_t W = scan_tmp[BIN_THREADS / 64 - 1];
       if (tid == 0) pref[BIN_CHUNK] = W;
       __syncthreads();
       for (uint32_t w = (uint32_t)tid; w < W; w += BIN_THREADS) {
@@ -124,31 +144,20 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restri
           qm = tile_quadrant_mask(c0, c1, c2, x0, y0, x1, y1, (tx0 + tx) * 64, (ty0 + ty) * 64);
         if (qm) {
           const uint32_t tile = (uint32_t)((ty0 + ty) * tiles_x + tx0 + tx);
-          if (pass == 0) {
-            atomicAdd(&tile_cnt[tile], 1u);
-          } else {
-            const uint32_t pos = atomicAdd(&tile_off[tile], 1u);
-            if (pos < entry_cap) pent[pos] = (cbase + lo) | (qm << 28);
-          }
+          atomicAdd(&tile_cnt[tile], 1u);
+          const uint32_t k = atomicAdd(&n_hits, 1u);  // (a pose with more than entry_cap pairs overflows below)
+          if (k < entry_cap) phits[k] = make_uint2((cbase + lo) | (qm << 28), tile);
         }
       }
     }
     __syncthreads();
-    if (pass == 1) break;
     // exclusive scan of tile_cnt -> tile_off (thread t owns T/512 consecutive tiles); headers out
     const uint32_t per = (T + BIN_THREADS - 1u) / BIN_THREADS, lo = min((uint32_t)tid * per, T), hi = min(lo + per, T);
     uint32_t sum = 0;
     for (uint32_t i = lo; i < hi; i++) sum += tile_cnt[i];
-    scan_tmp[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < BIN_THREADS; d <<= 1) {
-      const uint32_t v = tid >= d ? scan_tmp[tid - d] : 0u;
-      __syncthreads();
-      scan_tmp[tid] += v;
-      __syncthreads();
-    }
-    const uint32_t total = scan_tmp[BIN_THREADS - 1];
-    uint32_t run = scan_tmp[tid] - sum;
+    const uint32_t incl_t = block_scan<BIN_THREADS>(sum, scan_tmp);
+    const uint32_t total = scan_tmp[BIN_THREADS / 64 - 1];
+    uint32_t run = incl_t - sum;
     for (uint32_t i = lo; i < hi; i++) {
       tile_off[i] = run;
       hdr[i] = make_uint2(run, tile_cnt[i]);
@@ -156,6 +165,15 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restri
     }
     if (tid == 0) overflow[pose] = total > entry_cap ? 1u : 0u;
     if (total > entry_cap) return;  // uniform
+    __syncthreads();
+    // fill: the pairs are read back in the order they were found (near to far up to a window of BIN_CHUNK triangles)
+    for (uint32_t k0 = 0; k0 < total; k0 += BIN_THREADS) {
+      const uint32_t k = k0 + (uint32_t)tid;
+      if (k < total) {
+        const uint2 h = phits[k];
+        pent[atomicAdd(&tile_off[h.y], 1u)] = h.x;
+      }
+    }
   }
 }
 
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restri
 
 bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
                 uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
-                uint32_t *overflow) {
+                uint2 *hits, uint32_t *overflow) {
   const uint32_t bin_tiles = std::min<uint32_t>((uint32_t)(tiles_x * tiles_y), MAX_TILES);
   const int bin_threads = rdoom::debug_options().bin_threads;
   auto bk = bin_threads == 512 ? bin_kernel<512, 9> : (bin_threads == 128 ? bin_kernel<128, 7> : bin_kernel<256, 8>);
@@ -175,7 +193,7 @@ bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint
       attr.sharedSizeBytes + 2 * sizeof(uint32_t) * bin_tiles > 65536u || (uint32_t)(tiles_x * tiles_y) > MAX_TILES)
     return false;
   hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bt), 2 * sizeof(uint32_t) * bin_tiles, st, recs, sorted, counts, cap, tiles_x,
-                     tiles_y, tile_hdr, entries, entry_cap, overflow);
+                     tiles_y, tile_hdr, entries, entry_cap, hits, overflow);
   return true;
 }
 

@@ -24,7 +24,7 @@ size_t setup_histogram_bytes(uint32_t max_poses);  // scratch of the counting so
 // nothing was launched and the caller must flag every pose as "bins incomplete"
 bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
                 uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
-                uint32_t *overflow);
+                uint2 *hits, uint32_t *overflow);
 // Kernel 2: tiled rasteriser -> visibility words (raster.hip)
 rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,

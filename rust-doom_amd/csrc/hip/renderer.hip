@@ -41,6 +41,7 @@ struct rdoom_batch {
   uint4 *d_sorted = nullptr;  // per pose: (bbox, record index, depth bucket) near-to-far (coarse test input)
   uint2 *d_tile_hdr = nullptr;     // per (pose, tile): (first entry, entry count)
   uint32_t *d_entries = nullptr;   // per pose: entry_cap tile-list entries (record index | quadrant mask << 28)
+  uint2 *d_hits = nullptr;         // per pose: entry_cap (entry, tile) pairs: the binning kernel's count pass -> its fill pass
   uint32_t *d_overflow = nullptr;  // per pose: 1 = bins incomplete, rasteriser scans the sorted list
   uint32_t entry_cap = 0, n_tiles = 0;
   uint32_t *d_fix_count = nullptr;  // [0] = queued pixels, [1] = error flag (fixup list overflow)
@@ -285,7 +286,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
 
 void rdoom_batch_destroy(rdoom_batch *b) {
   if (!b) return;
-  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_visible, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries,
+  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_visible, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries, (void *)b->d_hits,
                   (void *)b->d_overflow, (void *)b->d_ghist, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb})
     if (p) (void)hipFree(p);
@@ -324,6 +325,7 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (dbg.entry_cap > 0) b->entry_cap = (uint32_t)dbg.entry_cap;  // tests: force that fallback
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_tile_hdr, sizeof(uint2) * (size_t)b->n_tiles * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_entries, sizeof(uint32_t) * (size_t)b->entry_cap * max_poses);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_hits, sizeof(uint2) * (size_t)b->entry_cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_overflow, sizeof(uint32_t) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_count, 2 * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_list, sizeof(uint2) * (size_t)b->fix_cap);
@@ -410,7 +412,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   if (!(lv->ntri && !rdoom::debug_options().no_bins &&
         launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
-                   b->entry_cap, b->d_overflow))) {
+                   b->entry_cap, b->d_hits, b->d_overflow))) {
     HIP_TRY(hipMemsetAsync(b->d_overflow, 0xFF, sizeof(uint32_t) * n, st));
     if (!lv->ntri) HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
   }
