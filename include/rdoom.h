@@ -204,12 +204,85 @@ rdoom_status rdoom_wad_level_name(const rdoom_wad *wad, uint32_t index, char out
 /* WadName::from_bytes (wad/src/name.rs:41-75); out = 8 bytes */
 rdoom_status rdoom_wad_name_from_bytes(const uint8_t *bytes, uint32_t len, uint8_t out[8]);
 
+/* ---- the reference's own plug-in point: trait wad::LevelVisitor (wad/src/visitor.rs:65-127) -------------------
+ * Thirteen callbacks, every one optional (NULL = the trait's default: do nothing).  Payloads mirror the structs of
+ * visitor.rs:24-63 and are BORROWED for the duration of the call (the walker reuses its scratch per sub-sector,
+ * visitor.rs:646-651): copy out what you keep.  Callbacks are infallible, as in the reference, and must not unwind
+ * or longjmp across the library.  `user` is handed back untouched. */
+typedef struct rdoom_light_info {   /* wad/src/light.rs:8-25 LightInfo { level, effect: Option<LightEffect> } */
+  float level;
+  int32_t has_effect;               /* 0: effect is None, the rest is unset */
+  int32_t effect_kind;              /* 0 Glow, 1 Random, 2 Alternate (LightEffectKind) */
+  float alt_level, speed, duration, sync;
+} rdoom_light_info;
+typedef struct rdoom_static_quad {  /* visitor.rs:24-34 */
+  uint32_t object_id;
+  float v1[2], v2[2];
+  float tex_start[2], tex_end[2], height_range[2];
+  const rdoom_light_info *light_info;
+  float scroll;
+  int32_t has_tex_name;             /* Option<WadName> */
+  uint8_t tex_name[8];
+  int32_t blocker;
+} rdoom_static_quad;
+typedef struct rdoom_static_poly {  /* visitor.rs:36-42 */
+  uint32_t object_id;
+  const float *vertices;            /* n_vertices x (x, z) */
+  uint32_t n_vertices;
+  float height;
+  const rdoom_light_info *light_info;
+  uint8_t tex_name[8];
+} rdoom_static_poly;
+typedef struct rdoom_sky_quad {     /* visitor.rs:44-48 */
+  uint32_t object_id;
+  float v1[2], v2[2], height_range[2];
+} rdoom_sky_quad;
+typedef struct rdoom_sky_poly {     /* visitor.rs:50-54 */
+  uint32_t object_id;
+  const float *vertices;
+  uint32_t n_vertices;
+  float height;
+} rdoom_sky_poly;
+typedef struct rdoom_decor {        /* visitor.rs:56-63 */
+  uint32_t object_id;
+  float low[3], high[3], half_width;
+  const rdoom_light_info *light_info;
+  uint8_t tex_name[8];
+} rdoom_decor;
+typedef struct rdoom_line2f {       /* math/src/line.rs:5-10 Line2 { origin, displace, length } */
+  float origin[2], displace[2], length;
+} rdoom_line2f;
+enum { RDOOM_MARKER_START_POS = 0, RDOOM_MARKER_TELEPORT_START = 1, RDOOM_MARKER_TELEPORT_END = 2 };  /* visitor.rs:129-133 */
+enum { RDOOM_BRANCH_POSITIVE = 0, RDOOM_BRANCH_NEGATIVE = 1 };                                        /* visitor.rs:135-139 */
+typedef struct rdoom_visitor_vtbl { /* trait LevelVisitor, method for method (visitor.rs:65-116) */
+  void (*visit_wall_quad)(void *user, const rdoom_static_quad *quad);
+  void (*visit_floor_poly)(void *user, const rdoom_static_poly *poly);
+  void (*visit_ceil_poly)(void *user, const rdoom_static_poly *poly);
+  void (*visit_floor_sky_poly)(void *user, const rdoom_sky_poly *poly);
+  void (*visit_ceil_sky_poly)(void *user, const rdoom_sky_poly *poly);
+  void (*visit_sky_quad)(void *user, const rdoom_sky_quad *quad);
+  void (*visit_marker)(void *user, const float pos[3], float yaw_rad, int32_t marker, uint32_t player);
+  void (*visit_decor)(void *user, const rdoom_decor *decor);
+  void (*visit_bsp_root)(void *user, const rdoom_line2f *line);
+  void (*visit_bsp_node)(void *user, const rdoom_line2f *line, int32_t branch);
+  void (*visit_bsp_leaf)(void *user, int32_t branch);
+  void (*visit_bsp_leaf_end)(void *user);
+  void (*visit_bsp_node_end)(void *user);
+} rdoom_visitor_vtbl;
+/* WadSystem::walk<V: LevelVisitor>(&self, &mut V) (game/src/wad_system.rs:47-56): LevelWalker::walk over one level with
+ * the caller's visitor only -- the way game::world::WorldBuilder is driven (game/src/world.rs:306). */
+rdoom_status rdoom_wad_walk(const rdoom_wad *wad, uint32_t level_index, const rdoom_visitor_vtbl *visitor, void *user);
+
 /* WadSystem::create's level half + GameShaders::load_level + Builder::build
  * (game/src/wad_system.rs:72-113, game/src/game_shaders.rs:175-387, game/src/level.rs:330-496).
  * use_gpu_tessellation != 0 runs the SSECTOR->polygon / SEG->quad kernels on the current device
  * (results are identical to the host walk). */
 rdoom_status rdoom_wad_build_level(const rdoom_wad *wad, uint32_t level_index, int32_t use_gpu_tessellation,
                                    rdoom_built **out_built);
+/* The same with a second visitor chained AFTER the Builder -- `builder.chain(&mut world_builder)` of
+ * game/src/level.rs:378-382 (VisitorChain, visitor.rs:1261-1331): each event reaches the Builder, then `visitor`. */
+rdoom_status rdoom_wad_build_level_chained(const rdoom_wad *wad, uint32_t level_index, int32_t use_gpu_tessellation,
+                                           const rdoom_visitor_vtbl *visitor, void *user, rdoom_built **out_built);
 void rdoom_built_destroy(rdoom_built *built);
 /* borrowed pointers into `built`, valid until rdoom_built_destroy */
 rdoom_status rdoom_built_desc(const rdoom_built *built, rdoom_level_desc *out_desc);

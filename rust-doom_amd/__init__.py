@@ -76,7 +76,7 @@ API_SYMBOLS = [
     'rdoom_wad_open', 'rdoom_wad_close', 'rdoom_wad_num_levels', 'rdoom_wad_level_name',
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
     'rdoom_built_counters', 'rdoom_built_lights_at', 'rdoom_built_start', 'rdoom_built_floor_centroids',
-    'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_debug_set', 'rdoom_batch_render_objects', 'rdoom_level_num_objects', 'rdoom_batch_enable_primitive_ids']
+    'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_debug_set', 'rdoom_wad_walk', 'rdoom_wad_build_level_chained', 'rdoom_batch_render_objects', 'rdoom_level_num_objects', 'rdoom_batch_enable_primitive_ids']
 
 _lib = None
 
@@ -189,6 +189,77 @@ def make_desc(arrays):
     return d, keep
 
 
+# ---- trait wad::LevelVisitor over the C ABI (include/rdoom.h: rdoom_visitor_vtbl) -----------------------------------
+class LightInfo(ctypes.Structure):
+    _fields_ = [('level', ctypes.c_float), ('has_effect', ctypes.c_int32), ('effect_kind', ctypes.c_int32),
+                ('alt_level', ctypes.c_float), ('speed', ctypes.c_float), ('duration', ctypes.c_float), ('sync', ctypes.c_float)]
+
+
+class StaticQuad(ctypes.Structure):
+    _fields_ = [('object_id', ctypes.c_uint32), ('v1', ctypes.c_float * 2), ('v2', ctypes.c_float * 2),
+                ('tex_start', ctypes.c_float * 2), ('tex_end', ctypes.c_float * 2), ('height_range', ctypes.c_float * 2),
+                ('light_info', ctypes.POINTER(LightInfo)), ('scroll', ctypes.c_float), ('has_tex_name', ctypes.c_int32),
+                ('tex_name', ctypes.c_uint8 * 8), ('blocker', ctypes.c_int32)]
+
+
+class StaticPoly(ctypes.Structure):
+    _fields_ = [('object_id', ctypes.c_uint32), ('vertices', ctypes.POINTER(ctypes.c_float)), ('n_vertices', ctypes.c_uint32),
+                ('height', ctypes.c_float), ('light_info', ctypes.POINTER(LightInfo)), ('tex_name', ctypes.c_uint8 * 8)]
+
+
+class SkyQuad(ctypes.Structure):
+    _fields_ = [('object_id', ctypes.c_uint32), ('v1', ctypes.c_float * 2), ('v2', ctypes.c_float * 2),
+                ('height_range', ctypes.c_float * 2)]
+
+
+class SkyPoly(ctypes.Structure):
+    _fields_ = [('object_id', ctypes.c_uint32), ('vertices', ctypes.POINTER(ctypes.c_float)), ('n_vertices', ctypes.c_uint32),
+                ('height', ctypes.c_float)]
+
+
+class Decor(ctypes.Structure):
+    _fields_ = [('object_id', ctypes.c_uint32), ('low', ctypes.c_float * 3), ('high', ctypes.c_float * 3),
+                ('half_width', ctypes.c_float), ('light_info', ctypes.POINTER(LightInfo)), ('tex_name', ctypes.c_uint8 * 8)]
+
+
+class Line2f(ctypes.Structure):
+    _fields_ = [('origin', ctypes.c_float * 2), ('displace', ctypes.c_float * 2), ('length', ctypes.c_float)]
+
+
+_VP = ctypes.c_void_p
+_VISITOR_SIGNATURES = [
+    ('visit_wall_quad', (ctypes.POINTER(StaticQuad),)), ('visit_floor_poly', (ctypes.POINTER(StaticPoly),)),
+    ('visit_ceil_poly', (ctypes.POINTER(StaticPoly),)), ('visit_floor_sky_poly', (ctypes.POINTER(SkyPoly),)),
+    ('visit_ceil_sky_poly', (ctypes.POINTER(SkyPoly),)), ('visit_sky_quad', (ctypes.POINTER(SkyQuad),)),
+    ('visit_marker', (ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.c_int32, ctypes.c_uint32)),
+    ('visit_decor', (ctypes.POINTER(Decor),)), ('visit_bsp_root', (ctypes.POINTER(Line2f),)),
+    ('visit_bsp_node', (ctypes.POINTER(Line2f), ctypes.c_int32)), ('visit_bsp_leaf', (ctypes.c_int32,)),
+    ('visit_bsp_leaf_end', ()), ('visit_bsp_node_end', ())]
+_VISITOR_TYPES = {name: ctypes.CFUNCTYPE(None, _VP, *args) for name, args in _VISITOR_SIGNATURES}
+
+
+class VisitorVtbl(ctypes.Structure):
+    _fields_ = [(name, _VISITOR_TYPES[name]) for name, _ in _VISITOR_SIGNATURES]
+
+
+def make_visitor(obj):
+    """rdoom_visitor_vtbl from any object: a method named like a callback of trait LevelVisitor (visitor.rs:65-116)
+    receives the payload (ctypes structure pointers are dereferenced); missing methods stay NULL = the trait's default.
+    Returns (vtbl, keepalive)."""
+    vt, keep = VisitorVtbl(), []
+    for name, args in _VISITOR_SIGNATURES:
+        fn = getattr(obj, name, None)
+        if fn is None:
+            continue
+
+        def thunk(_user, *a, _fn=fn):
+            _fn(*[x.contents if hasattr(x, 'contents') and not isinstance(x, ctypes.POINTER(ctypes.c_float)) else x for x in a])
+        cb = _VISITOR_TYPES[name](thunk)
+        keep.append(cb)
+        setattr(vt, name, cb)
+    return vt, keep
+
+
 class Wad:
     """wad::Archive + TextureDirectory behind rdoom_wad_open (wad/src/archive.rs:36-60, tex.rs:53-107)."""
 
@@ -213,17 +284,30 @@ class Wad:
         _check(lib().rdoom_wad_level_name(self._h, int(index), buf))
         return buf.value.decode('ascii')
 
-    def build_level(self, index, gpu_tessellation=False):
-        return BuiltLevel(self, index, gpu_tessellation)
+    def build_level(self, index, gpu_tessellation=False, visitor=None):
+        """visitor: an object with LevelVisitor methods, chained after the Builder (game/src/level.rs:378-382)"""
+        return BuiltLevel(self, index, gpu_tessellation, visitor)
+
+    def walk(self, index, visitor):
+        """WadSystem::walk (game/src/wad_system.rs:47-56) with the caller's visitor only"""
+        vt, keep = make_visitor(visitor)
+        _check(lib().rdoom_wad_walk(self._h, int(index), ctypes.byref(vt), None))
+        del keep
 
 
 class BuiltLevel:
     """Result of game::level::Builder::build + GameShaders::load_level (SURVEY section 8(b))."""
 
-    def __init__(self, wad, index, gpu_tessellation=False):
+    def __init__(self, wad, index, gpu_tessellation=False, visitor=None):
         self._h = ctypes.c_void_p()
         self._wad = wad
-        _check(lib().rdoom_wad_build_level(wad._h, int(index), int(bool(gpu_tessellation)), ctypes.byref(self._h)))
+        if visitor is None:
+            _check(lib().rdoom_wad_build_level(wad._h, int(index), int(bool(gpu_tessellation)), ctypes.byref(self._h)))
+        else:
+            vt, keep = make_visitor(visitor)
+            _check(lib().rdoom_wad_build_level_chained(wad._h, int(index), int(bool(gpu_tessellation)), ctypes.byref(vt), None,
+                                                       ctypes.byref(self._h)))
+            del keep
         self.desc = LevelDesc()
         _check(lib().rdoom_built_desc(self._h, ctypes.byref(self.desc)))
 

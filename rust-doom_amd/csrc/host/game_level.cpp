@@ -170,8 +170,16 @@ void Builder::visit_decor(const Decor &d) {  // level.rs:764-793
 }
 
 // ---- level assembly -------------------------------------------------------------------------------------
+void walk_level(const LoadedWad &w, size_t level_index, wad::LevelVisitor &visitor) {
+  const Archive &archive = *w.archive;
+  const Level level = Level::from_archive(archive, level_index);
+  const LevelAnalysis analysis(level, archive.metadata());
+  LevelWalker walker(level, analysis, w.textures, archive.metadata(), visitor);
+  walker.walk();
+}
+
 std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, TessellateFn tessellate,
-                                        TessellateSegsFn tessellate_segs) {
+                                        TessellateSegsFn tessellate_segs, wad::LevelVisitor *chained) {
   const Archive &archive = *w.archive;
   const TextureDirectory &tex = w.textures;
   const Level level = Level::from_archive(archive, level_index);
@@ -225,7 +233,9 @@ std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, 
   out->colormap.assign(tex.colormap(0), tex.colormap(0) + 32 * 256);
 
   Builder builder(materials);
-  LevelWalker walker(level, analysis, tex, archive.metadata(), builder);
+  LevelVisitor no_second;
+  VisitorChain chain(builder, chained ? *chained : no_second);  // builder.chain(..): level.rs:378-382
+  LevelWalker walker(level, analysis, tex, archive.metadata(), chained ? static_cast<LevelVisitor &>(chain) : builder);
   std::vector<std::vector<Pnt2f>> polygons;
   std::vector<wad::SegGeometry> seg_geometry;
   if (tessellate) {

@@ -92,7 +92,10 @@ using TessellateFn = std::vector<std::vector<wad::Pnt2f>> (*)(const wad::Level &
 // `tessellate_segs` (optional, with `tessellate`): called with the recorded per-seg inputs, returns the wall / sky
 // quad geometry computed on the GPU (indexed by seg).
 using TessellateSegsFn = std::vector<wad::SegGeometry> (*)(const std::vector<wad::SegInput> &);
+// `chained` (optional): a second visitor that sees every event after the Builder (game/src/level.rs:378-382).
 std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, TessellateFn tessellate,
-                                        TessellateSegsFn tessellate_segs = nullptr);
+                                        TessellateSegsFn tessellate_segs = nullptr, wad::LevelVisitor *chained = nullptr);
+// WadSystem::walk (game/src/wad_system.rs:47-56): one level, the caller's visitor only.
+void walk_level(const LoadedWad &w, size_t level_index, wad::LevelVisitor &visitor);
 
 }  // namespace rdoom::game

@@ -19,6 +19,113 @@ struct rdoom_built {
 };
 
 namespace {
+// trait LevelVisitor implemented by a table of C callbacks (include/rdoom.h: rdoom_visitor_vtbl)
+class CallbackVisitor : public rdoom::wad::LevelVisitor {
+ public:
+  CallbackVisitor(const rdoom_visitor_vtbl &v, void *user) : v_(v), user_(user) {}
+  void visit_wall_quad(const rdoom::wad::StaticQuad &q) override {
+    if (!v_.visit_wall_quad) return;
+    rdoom_light_info li;
+    rdoom_static_quad c{};
+    c.object_id = q.object_id.v;
+    xz(c.v1, q.v1), xz(c.v2, q.v2);
+    for (int i = 0; i < 2; i++) c.tex_start[i] = q.tex_start[i], c.tex_end[i] = q.tex_end[i], c.height_range[i] = q.height_range[i];
+    c.light_info = light(li, q.light_info);
+    c.scroll = q.scroll;
+    c.has_tex_name = q.tex_name ? 1 : 0;
+    if (q.tex_name) std::memcpy(c.tex_name, q.tex_name->b.data(), 8);
+    c.blocker = q.blocker ? 1 : 0;
+    v_.visit_wall_quad(user_, &c);
+  }
+  void visit_floor_poly(const rdoom::wad::StaticPoly &p) override { poly(v_.visit_floor_poly, p); }
+  void visit_ceil_poly(const rdoom::wad::StaticPoly &p) override { poly(v_.visit_ceil_poly, p); }
+  void visit_floor_sky_poly(const rdoom::wad::SkyPoly &p) override { sky_poly(v_.visit_floor_sky_poly, p); }
+  void visit_ceil_sky_poly(const rdoom::wad::SkyPoly &p) override { sky_poly(v_.visit_ceil_sky_poly, p); }
+  void visit_sky_quad(const rdoom::wad::SkyQuad &q) override {
+    if (!v_.visit_sky_quad) return;
+    rdoom_sky_quad c{};
+    c.object_id = q.object_id.v;
+    xz(c.v1, q.v1), xz(c.v2, q.v2);
+    c.height_range[0] = q.height_range[0], c.height_range[1] = q.height_range[1];
+    v_.visit_sky_quad(user_, &c);
+  }
+  void visit_marker(const float pos[3], float yaw, rdoom::wad::Marker m) override {
+    if (v_.visit_marker) v_.visit_marker(user_, pos, yaw, (int32_t)m.kind, (uint32_t)m.player);
+  }
+  void visit_decor(const rdoom::wad::Decor &d) override {
+    if (!v_.visit_decor) return;
+    rdoom_light_info li;
+    rdoom_decor c{};
+    c.object_id = d.object_id.v;
+    std::memcpy(c.low, d.low, 12), std::memcpy(c.high, d.high, 12);
+    c.half_width = d.half_width;
+    c.light_info = light(li, d.light_info);
+    std::memcpy(c.tex_name, d.tex_name.b.data(), 8);
+    v_.visit_decor(user_, &c);
+  }
+  void visit_bsp_root(const rdoom::wad::Line2f &l) override {
+    if (!v_.visit_bsp_root) return;
+    const rdoom_line2f c = line(l);
+    v_.visit_bsp_root(user_, &c);
+  }
+  void visit_bsp_node(const rdoom::wad::Line2f &l, rdoom::wad::Branch b) override {
+    if (!v_.visit_bsp_node) return;
+    const rdoom_line2f c = line(l);
+    v_.visit_bsp_node(user_, &c, (int32_t)b);
+  }
+  void visit_bsp_leaf(rdoom::wad::Branch b) override {
+    if (v_.visit_bsp_leaf) v_.visit_bsp_leaf(user_, (int32_t)b);
+  }
+  void visit_bsp_leaf_end() override {
+    if (v_.visit_bsp_leaf_end) v_.visit_bsp_leaf_end(user_);
+  }
+  void visit_bsp_node_end() override {
+    if (v_.visit_bsp_node_end) v_.visit_bsp_node_end(user_);
+  }
+
+ private:
+  static void xz(float out[2], rdoom::wad::Pnt2f p) { out[0] = p.x, out[1] = p.y; }
+  static rdoom_line2f line(const rdoom::wad::Line2f &l) {
+    return rdoom_line2f{{l.origin.x, l.origin.y}, {l.displace.x, l.displace.y}, l.length};
+  }
+  static const rdoom_light_info *light(rdoom_light_info &out, const rdoom::wad::LightInfo *in) {
+    if (!in) return nullptr;
+    out = rdoom_light_info{};
+    out.level = in->level;
+    if (in->effect) {
+      out.has_effect = 1;
+      out.effect_kind = (int32_t)in->effect->kind;
+      out.alt_level = in->effect->alt_level, out.speed = in->effect->speed, out.duration = in->effect->duration,
+      out.sync = in->effect->sync;
+    }
+    return &out;
+  }
+  void poly(void (*fn)(void *, const rdoom_static_poly *), const rdoom::wad::StaticPoly &p) {
+    if (!fn) return;
+    static_assert(sizeof(rdoom::wad::Pnt2f) == 2 * sizeof(float), "Pnt2f is two floats");
+    rdoom_light_info li;
+    rdoom_static_poly c{};
+    c.object_id = p.object_id.v;
+    c.vertices = reinterpret_cast<const float *>(p.vertices);
+    c.n_vertices = (uint32_t)p.n_vertices;
+    c.height = p.height;
+    c.light_info = light(li, p.light_info);
+    std::memcpy(c.tex_name, p.tex_name.b.data(), 8);
+    fn(user_, &c);
+  }
+  void sky_poly(void (*fn)(void *, const rdoom_sky_poly *), const rdoom::wad::SkyPoly &p) {
+    if (!fn) return;
+    rdoom_sky_poly c{};
+    c.object_id = p.object_id.v;
+    c.vertices = reinterpret_cast<const float *>(p.vertices);
+    c.n_vertices = (uint32_t)p.n_vertices;
+    c.height = p.height;
+    fn(user_, &c);
+  }
+  const rdoom_visitor_vtbl v_;
+  void *user_;
+};
+
 template <class F>
 rdoom_status guarded(F f) {
   try {
@@ -84,6 +191,30 @@ rdoom_status rdoom_wad_build_level(const rdoom_wad *wad, uint32_t level_index, i
                                     use_gpu_tessellation ? &rdoom::game::tessellate_on_device : nullptr,
                                     use_gpu_tessellation ? &rdoom::game::tessellate_segs_on_device : nullptr);
     *out_built = b.release();
+    return RDOOM_OK;
+  });
+}
+
+rdoom_status rdoom_wad_build_level_chained(const rdoom_wad *wad, uint32_t level_index, int32_t use_gpu_tessellation,
+                                           const rdoom_visitor_vtbl *visitor, void *user, rdoom_built **out_built) {
+  if (!wad || !out_built || !visitor) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out_built = nullptr;
+  return guarded([&]() -> rdoom_status {
+    CallbackVisitor second(*visitor, user);
+    auto b = std::make_unique<rdoom_built>();
+    b->b = rdoom::game::build_level(wad->w, level_index,
+                                    use_gpu_tessellation ? &rdoom::game::tessellate_on_device : nullptr,
+                                    use_gpu_tessellation ? &rdoom::game::tessellate_segs_on_device : nullptr, &second);
+    *out_built = b.release();
+    return RDOOM_OK;
+  });
+}
+
+rdoom_status rdoom_wad_walk(const rdoom_wad *wad, uint32_t level_index, const rdoom_visitor_vtbl *visitor, void *user) {
+  if (!wad || !visitor) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  return guarded([&]() -> rdoom_status {
+    CallbackVisitor v(*visitor, user);
+    rdoom::game::walk_level(wad->w, level_index, v);
     return RDOOM_OK;
   });
 }

@@ -108,3 +108,17 @@ def test_level_create_validates_before_touching_the_device():
     with pytest.raises(rd.RdoomError) as e:
         rd.DeviceLevel(bad)
     assert e.value.status == -1
+
+
+def test_integration_binding_is_the_generated_one():
+    """INTEGRATION.md's Rust block == tools/gen_rust_binding.py's output for the current header (no drift), and it
+    declares every entry point"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gen_rust_binding', os.path.join(ROOT, 'tools', 'gen_rust_binding.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = gen.generate()
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = doc[doc.index(gen.BEGIN) + len(gen.BEGIN):doc.index(gen.END)]
+    assert block.strip() == ('```rust\n' + text + '```').strip()
+    assert sorted(re.findall(r'pub fn (rdoom_\w+)\(', text)) == declared_functions()
