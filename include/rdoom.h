@@ -171,6 +171,12 @@ rdoom_status rdoom_batch_render_objects(rdoom_batch *batch, const rdoom_pose *po
                                         const float *object_modelviews, uint32_t n_objects);
 /* 1 + the largest rdoom_draw.object_id of the level */
 rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out);
+/* Waits for the batch's last render and returns ITS status: the asynchronous rdoom_batch_render cannot report what only
+ * the device finds out (today: the alpha-leak fixup list overflowing, which would leave leaked transparent texels in
+ * the frames).  Consumers of rdoom_batch_framebuffer_device call this -- or any of the rdoom_batch_read_* -- before
+ * trusting the frames; glFinish is the nearest reference counterpart. */
+rdoom_status rdoom_batch_finish(rdoom_batch *batch);
+
 /* device pointer to the n_poses*height*width palette-index framebuffers of the last render */
 rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **out_device_ptr);
 /* glReadPixels analogue: synchronises, copies frames [first, first+count) to host memory */

@@ -536,6 +536,8 @@ class TextureDirectory:
         bounds = {}
         for i, (name, img, frame_off, nframes) in enumerate(entries):
             atlas.blit(img, positions[i][0], positions[i][1], True)
+            if frame_off > i:  # tex.rs:258-261 indexes with usize: the reference panics; a negative Python index must not wrap
+                raise WadError('corrupt WAD: animated texture is missing its first frames')
             px, py, rh = positions[i - frame_off]  # tex.rs:258-261
             bounds[name] = Bounds((F(px), F(py)), (F(img.width), F(img.height)), nframes, rh)
         return atlas.pixels, bounds

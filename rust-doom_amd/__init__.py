@@ -72,7 +72,7 @@ class Counters(ctypes.Structure):
 API_SYMBOLS = [
     'rdoom_last_error', 'rdoom_device_count', 'rdoom_set_device', 'rdoom_level_create', 'rdoom_level_destroy',
     'rdoom_batch_create', 'rdoom_batch_destroy', 'rdoom_batch_render', 'rdoom_batch_render_timed',
-    'rdoom_batch_framebuffer_device', 'rdoom_batch_read_framebuffer', 'rdoom_batch_read_primitive_ids',
+    'rdoom_batch_framebuffer_device', 'rdoom_batch_finish', 'rdoom_batch_read_framebuffer', 'rdoom_batch_read_primitive_ids',
     'rdoom_wad_open', 'rdoom_wad_close', 'rdoom_wad_num_levels', 'rdoom_wad_level_name',
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
     'rdoom_built_counters', 'rdoom_built_lights_at', 'rdoom_built_start', 'rdoom_built_floor_centroids',
@@ -438,6 +438,10 @@ class Batch:
         t = Timings()
         _check(lib().rdoom_batch_render_timed(*args, ctypes.byref(t)))
         return {n: getattr(t, n) for n, _ in Timings._fields_}
+
+    def finish(self):
+        """rdoom_batch_finish: wait for the last render and raise if the device found a problem"""
+        _check(lib().rdoom_batch_finish(self._h))
 
     def framebuffer_device_ptr(self):
         p = ctypes.c_void_p()

@@ -81,10 +81,25 @@ void rdoom_level_destroy(rdoom_level *level) {
   delete level;
 }
 
+static rdoom_status level_create_impl(const rdoom_level_desc *d, rdoom_level **out_level);
+
 rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_level) {
+  try {  // std::vector / std::map below may throw: nothing unwinds across the C ABI
+    return level_create_impl(d, out_level);
+  } catch (const std::bad_alloc &) {
+    return rdoom::fail(RDOOM_OOM, "out of host memory");
+  } catch (const std::exception &e) {
+    return rdoom::fail(RDOOM_BAD_LEVEL, "%s", e.what());
+  }
+}
+
+static rdoom_status level_create_impl(const rdoom_level_desc *d, rdoom_level **out_level) {
   if (!d || !out_level) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   *out_level = nullptr;
   if (!d->colormap) return rdoom::fail(RDOOM_BAD_ARG, "colormap is null");
+  if ((d->flat_atlas && !(d->flat_w && d->flat_h)) || (d->wall_atlas && !(d->wall_w && d->wall_h)) ||
+      (d->decor_atlas && !(d->decor_w && d->decor_h)))
+    return rdoom::fail(RDOOM_BAD_ARG, "an atlas pointer is set but its size is zero");
   if ((d->flat_w | d->flat_h) && !(is_pow2(d->flat_w) && is_pow2(d->flat_h)))
     return rdoom::fail(RDOOM_BAD_ARG, "flat atlas %ux%u is not a power of two", d->flat_w, d->flat_h);
   if ((d->wall_w | d->wall_h) && !(is_pow2(d->wall_w) && is_pow2(d->wall_h)))
@@ -167,6 +182,7 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
         lt.packed = (uint32_t)pv.a_num_frames | ((uint32_t)pv.a_light << 8) | (dr.kind << 16) |
                     (masked << 18);
       } else if (dr.kind == RDOOM_KIND_SKY) {
+        if (!d->sky_texture || !d->sky_w || !d->sky_h) return rdoom::fail(RDOOM_BAD_ARG, "sky draw without a sky texture");
         if ((uint64_t)dr.first_index + dr.index_count > d->n_sky_indices)
           return rdoom::fail(RDOOM_BAD_ARG, "draw %u: sky index range out of bounds", di);
         for (int i = 0; i < 3; i++) {
@@ -307,6 +323,7 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (width == 0 || height == 0 || max_poses == 0 || width % 4 != 0 || width > 16384 || height > 16384)
     return rdoom::fail(RDOOM_BAD_ARG, "bad frame size %ux%u (width must be a multiple of 4) or max_poses %u", width,
                        height, max_poses);
+  HIP_TRY(hipSetDevice(level->device));  // the batch lives on the level's device, whatever the caller's current one is
   rdoom_batch *b = new rdoom_batch;
   b->level = level;
   b->width = width;
@@ -366,6 +383,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   if (!b || !poses || !lights) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   if (n == 0 || n > b->max_poses) return rdoom::fail(RDOOM_BAD_ARG, "n_poses %u outside 1..%u", n, b->max_poses);
   const rdoom_level *lv = b->level;
+  HIP_TRY(hipSetDevice(lv->device));  // level, scratch and kernels on one device (several GPUs driven from one process)
   if (object_modelviews && n_objects < lv->n_objects)
     return rdoom::fail(RDOOM_BAD_ARG, "n_objects %u but the level draws objects 0..%u", n_objects, lv->n_objects - 1);
   HIP_TRY(hipEventSynchronize(b->ev_copy));  // previous render's H2D must be done before restaging
@@ -470,6 +488,16 @@ rdoom_status rdoom_batch_render_objects(rdoom_batch *batch, const rdoom_pose *po
 rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out) {
   if (!level || !out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   *out = level->n_objects;
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_batch_finish(rdoom_batch *b) {
+  if (!b) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  HIP_TRY(hipSetDevice(b->level->device));
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t fix[2] = {0, 0};
+  HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
+  if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
   return RDOOM_OK;
 }
 

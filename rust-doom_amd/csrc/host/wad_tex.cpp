@@ -289,7 +289,12 @@ std::pair<TransparentImage, BoundsLookup> TextureDirectory::build_texture_atlas(
   Image atlas(size[0], size[1]);
   for (size_t i = 0; i < entries.size(); i++) {
     atlas.blit(*entries[i].image, positions[i].x, positions[i].y, true);
-    const Pos &p = positions[i - entries[i].frame_offset];  // every frame reports frame 0's place (tex.rs:258-261)
+    // every frame reports frame 0's place (tex.rs:258-261).  An animation whose earlier frames are missing from the
+    // WAD has frame_offset > i: the reference panics on the index (usize underflow); here it is a corrupt-WAD error
+    if (entries[i].frame_offset > i)
+      throw WadError(RDOOM_CORRUPT_WAD, "animated texture is missing its first frames (frame " +
+                                            std::to_string(entries[i].frame_offset) + " without its predecessors)");
+    const Pos &p = positions[i - entries[i].frame_offset];
     out.second.insert(entries[i].name, Bounds{{(float)p.x, (float)p.y},
                                               {(float)entries[i].image->width(), (float)entries[i].image->height()},
                                               entries[i].num_frames,

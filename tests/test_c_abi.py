@@ -122,3 +122,22 @@ def test_integration_binding_is_the_generated_one():
     block = doc[doc.index(gen.BEGIN) + len(gen.BEGIN):doc.index(gen.END)]
     assert block.strip() == ('```rust\n' + text + '```').strip()
     assert sorted(re.findall(r'pub fn (rdoom_\w+)\(', text)) == declared_functions()
+
+
+def test_level_create_rejects_sky_draws_without_a_sky_texture_and_empty_atlases():
+    """a descriptor the reference could never produce must come back as RDOOM_BAD_ARG, not fault on the device"""
+    from test_kat_analytic import kat_level
+    lvl, _ = kat_level()
+    bad = dict(lvl)
+    bad['sky_vertices'] = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    bad['sky_indices'] = np.array([0, 1, 2], np.uint32)
+    bad['draws'] = np.concatenate([np.asarray(lvl['draws'], np.uint32).reshape(-1, 4), [[3, 0, 0, 3]]]).astype(np.uint32)
+    bad['sky_texture'] = np.zeros((0, 0), np.uint16)
+    with pytest.raises(rd.RdoomError) as e:
+        rd.DeviceLevel(bad)
+    assert e.value.status == -1 and 'sky' in str(e.value)
+    desc, _keep = rd.make_desc(lvl)
+    desc.wall_w = 0  # pointer set, size zero
+    with pytest.raises(rd.RdoomError) as e:
+        rd.DeviceLevel(desc)
+    assert e.value.status == -1
