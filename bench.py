@@ -199,26 +199,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(acc=None):
-        for _built, _level, batch, poses, lights in work:
-            if n_mine == 0:
-                continue
-            t = batch.render(poses, lights, timed=True)    # hipEvents on the render stream, per kernel
-            if acc is not None:
+    # Steps are queued without a host synchronisation in between (the staging of step i + 1 overlaps the kernels of
+    # step i); the hipEvents around every kernel of every timed step stay pending on the render stream and are read
+    # after the closing barrier (at most 64 renders per batch may be pending: collected in between if K is larger).
+    def collect(acc):
+        for _built, _level, batch, _poses, _lights in work:
+            t = batch.collect_timings()
+            if acc is not None and t['renders']:
                 for k in ('setup_ms', 'raster_ms', 'fragment_ms'):
                     acc[k] += t[k]
-                acc['visible_triangles'] = acc.get('visible_triangles', 0) + t['visible_triangles']
-                acc['fixup_pixels'] = acc.get('fixup_pixels', 0) + t['fixup_pixels']
+                acc['visible_triangles'] = acc.get('visible_triangles', 0) + t['visible_triangles'] * t['renders']
+                acc['fixup_pixels'] = acc.get('fixup_pixels', 0) + t['fixup_pixels'] * t['renders']
 
-    for _ in range(args.warmup):
-        step()
+    def step(i):
+        for _built, _level, batch, poses, lights in work:
+            if n_mine:
+                batch.render_profiled(poses, lights)
+        if i % 60 == 59:
+            return True
+        return False
+
+    for i in range(args.warmup):
+        if step(i):
+            collect(None)
+    collect(None)
     barrier()
     t_start = time.perf_counter()
     acc = {'setup_ms': 0.0, 'raster_ms': 0.0, 'fragment_ms': 0.0}
-    for _ in range(args.steps):
-        step(acc)
+    for i in range(args.steps):
+        if step(i):
+            collect(acc)   # (a host synchronisation every 60 steps)
     barrier()
     elapsed = time.perf_counter() - t_start
+    collect(acc)
     elapsed = sharding.max_over_ranks(elapsed, dist, 'cuda' if backend == 'nccl' else 'cpu')
 
     if rank == 0:

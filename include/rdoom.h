@@ -161,6 +161,13 @@ rdoom_status rdoom_batch_render(rdoom_batch *batch, const rdoom_pose *poses, con
 rdoom_status rdoom_batch_render_timed(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
                                       uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
                                       rdoom_timings *out);
+/* Asynchronous like rdoom_batch_render, but the four hipEvents around the kernels are kept (up to 64 renders may be
+ * pending); rdoom_batch_collect_timings waits for the last of them and returns the SUMS over the pending renders
+ * (pixels = all their pixels; visible_triangles / fixup_pixels of the last one) and their number.  For profiling a
+ * pipelined sequence of renders without a host synchronisation in between (bench.py). */
+rdoom_status rdoom_batch_render_profiled(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                         uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream);
+rdoom_status rdoom_batch_collect_timings(rdoom_batch *batch, rdoom_timings *out_sums, uint32_t *out_renders);
 /* Same with moving objects (doors, lifts): the reference sets u_modelview = view o model transform for the draws
  * of each object (engine/src/renderer.rs:120-132; game/src/level.rs:203-255 moves the transforms).
  * object_modelviews: n_poses x n_objects column-major matrices, entry [p][o] = the u_modelview of object o's draws

@@ -71,7 +71,7 @@ class Counters(ctypes.Structure):
 # every symbol include/rdoom.h declares (tests check the library exports all of them)
 API_SYMBOLS = [
     'rdoom_last_error', 'rdoom_device_count', 'rdoom_set_device', 'rdoom_level_create', 'rdoom_level_destroy',
-    'rdoom_batch_create', 'rdoom_batch_destroy', 'rdoom_batch_render', 'rdoom_batch_render_timed',
+    'rdoom_batch_create', 'rdoom_batch_destroy', 'rdoom_batch_render', 'rdoom_batch_render_timed', 'rdoom_batch_render_profiled', 'rdoom_batch_collect_timings',
     'rdoom_batch_framebuffer_device', 'rdoom_batch_finish', 'rdoom_batch_read_framebuffer', 'rdoom_batch_read_primitive_ids',
     'rdoom_wad_open', 'rdoom_wad_close', 'rdoom_wad_num_levels', 'rdoom_wad_level_name',
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
@@ -418,6 +418,21 @@ class Batch:
             assert lights.size == 256 * len(poses), 'lights must be (256,) or (n_poses, 256)'
             stride = 256
         return poses, lights, stride
+
+    def render_profiled(self, poses, lights, kinds=ALL_KINDS, stream=None):
+        """rdoom_batch_render_profiled: asynchronous, the per-kernel events stay pending (at most 64 renders)"""
+        poses, lights, stride = self._prep(poses, lights)
+        self.last_n = len(poses)
+        _check(lib().rdoom_batch_render_profiled(self._h, poses.ctypes.data_as(ctypes.c_void_p), lights.ctypes.data_as(ctypes.c_void_p),
+                                                 stride, len(poses), int(kinds), ctypes.c_void_p(stream or 0)))
+
+    def collect_timings(self):
+        """rdoom_batch_collect_timings: sums over the pending profiled renders + their number"""
+        t, n = Timings(), ctypes.c_uint32()
+        _check(lib().rdoom_batch_collect_timings(self._h, ctypes.byref(t), ctypes.byref(n)))
+        out = {k: getattr(t, k) for k, _ in Timings._fields_}
+        out['renders'] = n.value
+        return out
 
     def render(self, poses, lights, kinds=ALL_KINDS, stream=None, timed=False, object_modelviews=None):
         """rdoom_batch_render(_timed): asynchronous unless timed; returns Timings fields when timed.

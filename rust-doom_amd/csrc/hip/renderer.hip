@@ -53,6 +53,9 @@ struct rdoom_batch {
   PoseConst *h_poses = nullptr;  // pinned staging for the per-pose constants
   ObjectConst *d_objects = nullptr, *h_objects = nullptr;  // max_poses x n_objects, allocated on first use
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr uint32_t RING = 64;  // renders whose per-kernel events may be pending (rdoom_batch_render_profiled)
+  hipEvent_t ring[RING][4] = {};
+  uint32_t ring_n = 0, ring_poses = 0;
   hipEvent_t ev_copy = nullptr;  // H2D of h_poses finished: staging may be rewritten
   bool want_prim = false;
   bool vis16 = false;  // record indices fit 16 bits: visibility words are u16
@@ -308,6 +311,9 @@ void rdoom_batch_destroy(rdoom_batch *b) {
     if (p) (void)hipFree(p);
   for (auto &e : b->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto &slot : b->ring)
+    for (auto &e : slot)
+      if (e) (void)hipEventDestroy(e);
   if (b->ev_copy) (void)hipEventDestroy(b->ev_copy);
   if (b->h_poses) (void)hipHostFree(b->h_poses);
   if (b->h_objects) (void)hipHostFree(b->h_objects);
@@ -379,7 +385,7 @@ static void mat_mul_v1(const float *P, const float *M, float *pm) {  // V1: PM =
 
 static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const uint8_t *lights, uint32_t lights_stride,
                                 uint32_t n, uint32_t kinds_mask, hipStream_t st, rdoom_timings *tm,
-                                const float *object_modelviews = nullptr, uint32_t n_objects = 0) {
+                                const float *object_modelviews = nullptr, uint32_t n_objects = 0, bool profiled = false) {
   if (!b || !poses || !lights) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   if (n == 0 || n > b->max_poses) return rdoom::fail(RDOOM_BAD_ARG, "n_poses %u outside 1..%u", n, b->max_poses);
   const rdoom_level *lv = b->level;
@@ -415,7 +421,15 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     std::memcpy(pc.lights, lights + (size_t)p * lights_stride, 256);
   }
   b->last_n = n;
-  if (tm) HIP_TRY(hipEventRecord(b->ev[0], st));
+  hipEvent_t *ev = b->ev;  // the four marks of this render: the batch's own, or a slot of the ring when nobody waits
+  if (profiled) {
+    if (b->ring_n == rdoom_batch::RING) return rdoom::fail(RDOOM_BAD_ARG, "%u profiled renders pending: collect the timings first", b->ring_n);
+    ev = b->ring[b->ring_n];
+    for (int k = 0; k < 4; k++)
+      if (!ev[k]) HIP_TRY(hipEventCreate(&ev[k]));
+  }
+  const bool marks = tm || profiled;
+  if (marks) HIP_TRY(hipEventRecord(ev[0], st));
   HIP_TRY(hipMemcpyAsync(b->d_poses, b->h_poses, sizeof(PoseConst) * n, hipMemcpyHostToDevice, st));
   if (object_modelviews)
     HIP_TRY(hipMemcpyAsync(b->d_objects, b->h_objects, sizeof(ObjectConst) * (size_t)n * lv->n_objects,
@@ -434,17 +448,22 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     HIP_TRY(hipMemsetAsync(b->d_overflow, 0xFF, sizeof(uint32_t) * n, st));
     if (!lv->ntri) HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
   }
-  if (tm) HIP_TRY(hipEventRecord(b->ev[1], st));
+  if (marks) HIP_TRY(hipEventRecord(ev[1], st));
   uint32_t *prim_out = b->want_prim ? b->d_prim : nullptr;
   if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, W, H, tiles_x, tiles_y,
                                       b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out))
     return rs;
-  if (tm) HIP_TRY(hipEventRecord(b->ev[2], st));
+  if (marks) HIP_TRY(hipEventRecord(ev[2], st));
   if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, b->d_poses, W, H, tiles_x,
                                         tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16,
                                         prim_out, b->d_ndc, b->d_fb, b->d_fix_count, b->d_fix_list, b->fix_cap))
     return rs;
   HIP_TRY(hipGetLastError());
+  if (profiled) {
+    HIP_TRY(hipEventRecord(ev[3], st));
+    b->ring_n++;
+    b->ring_poses += n;
+  }
   if (tm) {
     HIP_TRY(hipEventRecord(b->ev[3], st));
     HIP_TRY(hipEventSynchronize(b->ev[3]));
@@ -475,6 +494,38 @@ rdoom_status rdoom_batch_render_timed(rdoom_batch *batch, const rdoom_pose *pose
                                       rdoom_timings *out) {
   if (!out) return rdoom::fail(RDOOM_BAD_ARG, "out is null");
   return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, out);
+}
+
+rdoom_status rdoom_batch_render_profiled(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
+                                         uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream) {
+  return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, nullptr, nullptr, 0, true);
+}
+
+rdoom_status rdoom_batch_collect_timings(rdoom_batch *b, rdoom_timings *out, uint32_t *out_renders) {
+  if (!b || !out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out = rdoom_timings{};
+  if (out_renders) *out_renders = b->ring_n;
+  if (b->ring_n == 0) return RDOOM_OK;
+  HIP_TRY(hipSetDevice(b->level->device));
+  HIP_TRY(hipEventSynchronize(b->ring[b->ring_n - 1][3]));
+  for (uint32_t i = 0; i < b->ring_n; i++) {
+    float a = 0, r = 0, f = 0, t = 0;
+    HIP_TRY(hipEventElapsedTime(&a, b->ring[i][0], b->ring[i][1]));
+    HIP_TRY(hipEventElapsedTime(&r, b->ring[i][1], b->ring[i][2]));
+    HIP_TRY(hipEventElapsedTime(&f, b->ring[i][2], b->ring[i][3]));
+    HIP_TRY(hipEventElapsedTime(&t, b->ring[i][0], b->ring[i][3]));
+    out->setup_ms += a, out->raster_ms += r, out->fragment_ms += f, out->total_ms += t;
+  }
+  out->pixels = (uint64_t)b->ring_poses * b->width * b->height;
+  std::vector<uint32_t> counts(b->last_n);  // of the last render
+  HIP_TRY(hipMemcpy(counts.data(), b->d_counts, sizeof(uint32_t) * b->last_n, hipMemcpyDeviceToHost));
+  for (uint32_t c : counts) out->visible_triangles += c;
+  uint32_t fix[2] = {0, 0};
+  HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
+  out->fixup_pixels = fix[0];
+  b->ring_n = 0, b->ring_poses = 0;
+  if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
+  return RDOOM_OK;
 }
 
 rdoom_status rdoom_batch_render_objects(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
