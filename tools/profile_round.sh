@@ -1,7 +1,9 @@
 #!/bin/bash
-# Round profile on the GPU box (run from the repo root through gpurun):
-#   1. rocprofv3 --kernel-trace --stats over the default `python bench.py` command  -> gpurun_out/<tag>/stats
-#   2. PMC passes (counters only, separate runs) for HBM traffic of the fragment kernel -> gpurun_out/<tag>/pmc*
+# Round profile on the GPU box (run from the repo root through gpurun):  tools/profile_round.sh <tag>
+#   1. rocprofv3 --kernel-trace --stats over the default `python bench.py` command      -> gpurun_out/<tag>/stats
+#   2. PMC passes (counters in their own runs: --pmc + --kernel-trace only)              -> gpurun_out/<tag>/pmc*
+#   3. the un-profiled bench lines: default (BASELINE config 3), other frame sizes, the level sweep (config 4 on one
+#      GPU), the MAP29-class line (config 5), two ranks wrapped onto this one GPU (weak and strong)
 # Then locally:  python tools/profile_collect.py <tag> <round>   copies the summaries into profiles/.
 set -u
 TAG=${1:-prof}
@@ -23,3 +25,10 @@ done
 cd $ROOT
 python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 tail -1 $OUT/bench_plain.json
+: > $OUT/bench_other.jsonl
+for ARGS in "--width 3840 --height 2160 --poses 256" "--width 1280 --height 720 --poses 2048" "--width 320 --height 200 --poses 8192" \
+            "--big" "--big --width 3840 --height 2160 --poses 256 --time-varying" "--levels 0-8 --poses 512" \
+            "--gpus 2" "--gpus 2 --scaling strong"; do
+  python bench.py $ARGS --steps 10 --warmup 2 --cpu-sample 0 2>/dev/null | grep '^{' | tail -1 >> $OUT/bench_other.jsonl
+done
+wc -l $OUT/bench_other.jsonl
