@@ -219,6 +219,17 @@ __device__ __forceinline__ void raster_entry(const DeviceLevelView &lv, const Tr
 //                 triangle runs a depth-only pixel body.
 // A tile with more than 64 entries re-gathers each 64-entry batch once per quadrant.
 // =================================================================================================
+// max of v over the wavefront (DPP within rows of 16 lanes, then the four row results): uniform
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // quad_perm [2, 3, 0, 1]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));  // row_mirror
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                 c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                              const uint4 *__restrict__ sorted,
@@ -349,15 +360,25 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
       // ---- walk: the entries that touch this quadrant, near to far -------------------------------------------
       const uint32_t dnq = q == 0 ? dnq0 : (q == 1 ? dnq1 : (q == 2 ? dnq2 : dnq3));
       const unsigned long long qcm = __ballot(((myqb >> (4 + q)) & 1u) != 0u);
-      for (unsigned long long wm = __ballot(((myqb >> q) & 1u) != 0u); wm; wm &= wm - 1ull) {
+      // An entry is hidden in the whole quadrant when its nearest depth over the quadrant (lane s holds entry s's) is
+      // beyond the farthest depth ANY lane still holds: all entries are tested at once against that wave-wide maximum,
+      // again whenever a body has brought some lane's depths nearer.
+      const unsigned long long touch = __ballot(((myqb >> q) & 1u) != 0u);
+      uint32_t wave_far = wave_max_u32(lane_far);
+      unsigned long long wm = touch & __ballot(dnq <= wave_far);
+      if (STATS) st[0] += (unsigned long long)__popcll(touch), st[15] += (unsigned long long)__popcll(touch & ~wm);
+      while (wm) {
         const uint32_t s = (uint32_t)__builtin_ctzll(wm);
-        if (STATS) st[0]++;
-        const uint32_t dq = (uint32_t)__builtin_amdgcn_readlane((int)dnq, (int)s);
-        // hidden in the whole quadrant: every lane's nearest depth is >= dq (its block lies inside the quadrant)
-        if (!__any(dq <= lane_far)) {
-          if (STATS) st[15]++;
-          continue;
-        }
+        wm &= wm - 1ull;
+        const uint32_t far_before = lane_far;
+        auto refresh = [&]() {  // after a body: drop what is hidden now
+          if (__any(lane_far != far_before)) {
+            wave_far = wave_max_u32(lane_far);
+            const unsigned long long alive = __ballot(dnq <= wave_far);
+            if (STATS) st[15] += (unsigned long long)__popcll(wm & ~alive);
+            wm &= alive;
+          }
+        };
         if (STATS) st[1]++;
         auto bc = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)s); };
         auto bf = [&](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, (int)s)); };
@@ -391,7 +412,10 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
             for (int k = 1; k < 16; k++) m = max(m, best_d[k]);
             lane_far = m;
           }
-          if (!__any(tiez == 0u)) continue;
+          if (!__any(tiez == 0u)) {
+            refresh();
+            continue;
+          }
         }
         // the rest of the record: uniform LDS reads, made SGPR operands
         const uint4 *wr = wrec[wave][s];
@@ -403,6 +427,7 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
         raster_entry<STATS>(lv, prec, uf(r0.x), uf(r0.y), uf(r0.z), uf(r0.w), uf(r1.x), uf(r1.y), uf(r1.z), uf(r1.w),
                                  uf(r3.x), za, zb, zc, uf(r2.x), uf(r2.y), uf(r2.z), x0, y0, x1, y1, flags, ridx, bx, by, pxlo,
                                  pxhi, pylo, pyhi, best_d, best_r, lane_far, [&]() -> ShadeRec { return prec[ridx].s; }, st);
+        refresh();
       }
     }
     // ---- this quadrant's visibility words ------------------------------------------------------------------------
