@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
             }
           }
         }
-        if (STATS && !binned) st[8] += (unsigned long long)__popcll(__ballot(i < count)), st[9] += (unsigned long long)__popcll(__ballot(qb != 0u));
+
         const unsigned long long rm = __ballot(qb != 0u);
         n = (uint32_t)__popcll(rm);
         if (n != 0u) {
@@ -364,6 +364,27 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
       // beyond the farthest depth ANY lane still holds: all entries are tested at once against that wave-wide maximum,
       // again whenever a body has brought some lane's depths nearer.
       const unsigned long long touch = __ballot(((myqb >> q) & 1u) != 0u);
+      if (single && touch != 0ull) {
+        // Shortcut for the commonest quadrant of all: its nearest entry covers it entirely and every other entry of the
+        // (complete, single-batch) list lies strictly behind that entry's FARTHEST depth over the quadrant -- the entry
+        // wins all 1024 pixels without a compare (extremes of the computed depth sit at corners; strictness rules out ties).
+        const uint32_t s0 = (uint32_t)__builtin_ctzll(touch);
+        if ((qcm >> s0) & 1ull) {
+          const float za0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpa, (int)s0)),
+                      zb0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpb, (int)s0)),
+                      zc0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpc, (int)s0));
+          const float xl = (float)qx0 + 0.5f, xh = (float)qx0 + 31.5f, yl = (float)qy0 + 0.5f, yh = (float)qy0 + 31.5f;
+          const float zf0 = fmaf(za0, pos(za0) ? xh : xl, fmaf(zb0, pos(zb0) ? yh : yl, zc0));  // in [0, 1]: the entry covers
+          const uint32_t df0 = __float2uint_rz(fmaf(zf0, 16777215.0f, 0.5f));
+          if ((__ballot(dnq <= df0) & touch & ~(1ull << s0)) == 0ull) {
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)myrec, (int)s0);
+#pragma unroll
+            for (int k = 0; k < 16; k++) best_r[k] = r0;
+            if (STATS) st[0] += (unsigned long long)__popcll(touch), st[9]++;
+            continue;  // (the only batch: on to the visibility words)
+          }
+        }
+      }
       uint32_t wave_far = wave_max_u32(lane_far);
       unsigned long long wm = touch & __ballot(dnq <= wave_far);
       if (STATS) st[0] += (unsigned long long)__popcll(touch), st[15] += (unsigned long long)__popcll(touch & ~wm);
@@ -485,11 +506,10 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
     const double waves = (double)((n + 7) / 8) * 8.0 * (double)(tiles_x * tiles_y) * 4.0;  // (pose, quadrant) passes
     fprintf(stderr,
             "[rdoom stats] per quadrant pass: queue %.1f  past quadrant early-z %.1f  quadrant-cover %.2f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
-            "  general %.3f (lanes %.1f: masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | coarse tests/block %.0f hits %.1f\n",
+            "  general %.3f (lanes %.1f: masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | one-entry shortcut %.3f\n",
             h[0] / waves, h[1] / waves, h[10] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
             h[4] ? (double)h[5] / h[4] : 0.0, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
-            h[6] ? (double)h[12] / h[6] : 0.0, h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves,
-            (double)h[8] / (double)nblocks, (double)h[9] / (double)nblocks);
+            h[6] ? (double)h[12] / h[6] : 0.0, h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, h[9] / waves);
   }
   return RDOOM_OK;
 }
