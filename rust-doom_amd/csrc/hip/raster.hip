@@ -264,12 +264,132 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
   // what lane s keeps of the s-th entry of the current batch: record index, quadrant bits (touches: 0..3, covers:
   // 4..7), the depth plane, the nearest depth over each quadrant
   uint32_t n = 0, myrec = 0, myqb = 0, zpa = 0, zpb = 0, zpc = 0, dnq0 = NONE, dnq1 = NONE, dnq2 = NONE, dnq3 = NONE;
+  // Gathers one batch of 64 list entries into the lanes (see the header: candidates, ranking, records, the per-quadrant
+  // nearest depths and cover flags).  The usual tile has one batch, gathered once for its four quadrants.
+  auto gather = [&](uint32_t base) {
+    // ---- candidates: one per lane ----------------------------------------------------------------
+    const uint32_t i = base + (uint32_t)lane;
+    uint32_t cand = 0, qb = 0;
+    if (i < count) {
+      if (binned) {
+        const uint32_t e = pent[i];
+        cand = e & 0x0FFFFFFFu;
+        qb = e >> 28;  // exact quadrant tests done by the binning kernel
+      } else {
+        // pose without complete bins: every visible triangle is a candidate; bbox, then the exact quadrant tests
+        const uint4 bb = psorted[i];  // (bb0, bb1, record index, depth bucket), near to far
+        cand = bb.z;
+        const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
+        if (x0 <= tx0 + 63 && x1 >= tx0 && y0 <= ty0 + 63 && y1 >= ty0) {
+          const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[cand]);
+          qb = tile_quadrant_mask(rp[0], rp[1], rp[2], x0, y0, x1, y1, tx0, ty0);
+        }
+      }
+    }
+
+    const unsigned long long rm = __ballot(qb != 0u);
+    n = (uint32_t)__popcll(rm);
+    if (n != 0u) {
+      // rank of my entry among the relevant ones (record index = depth rank; the lists are near-sorted already)
+      uint32_t rank = 0;
+      for (unsigned long long m = rm; m; m &= m - 1ull) {
+        const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(m));
+        rank += kj < cand ? 1u : 0u;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier readers of myq / wrec are done
+      if (qb != 0u) myq[rank] = cand | (qb << 28);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // ---- records: lane s gathers entry s -------------------------------------------------------
+      const bool have = (uint32_t)lane < n;
+      myrec = 0u, myqb = 0u, zpa = zpb = zpc = 0u, dnq0 = dnq1 = dnq2 = dnq3 = NONE;
+      if (have) {
+        const uint32_t e = myq[lane];
+        myrec = e & 0x0FFFFFFFu;
+        myqb = e >> 28;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[myrec]);
+        const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3];
+        const uint2 c4 = *reinterpret_cast<const uint2 *>(rp + 4);
+        uint4 *mine = wrec[wave][lane];
+        mine[0] = c0, mine[1] = c1, mine[2] = c3, mine[3] = make_uint4(c2.x, c4.x, c4.y, 0u);
+        zpa = c2.y, zpb = c2.z, zpc = c2.w;
+        // per quadrant: nearest depth of my entry's plane over it as d24 (none if beyond far), and whether my
+        // entry covers it entirely -- the smallest computed value of each edge function and of 1/w and the
+        // extremes of the depth over the quadrant sit at corners (fmaf is monotone in each argument)
+        const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
+                    e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
+                    e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x);
+        const float za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
+        const float wa = __uint_as_float(c3.x), wb = __uint_as_float(c3.y), wc = __uint_as_float(c3.z);
+        const int x0 = (int)(c3.w & 0xFFFFu), y0 = (int)(c3.w >> 16), x1 = (int)(c4.x & 0xFFFFu), y1 = (int)(c4.x >> 16);
+        uint32_t dn[4];
+#pragma unroll
+        for (int qi = 0; qi < 4; qi++) {
+          const int rx0 = tx0 + (qi & 1) * 32, ry0 = ty0 + (qi >> 1) * 32;
+          const float xl = (float)rx0 + 0.5f, xh = (float)rx0 + 31.5f, yl = (float)ry0 + 0.5f, yh = (float)ry0 + 31.5f;
+          const float zn = fmaf(za, pos(za) ? xl : xh, fmaf(zb, pos(zb) ? yl : yh, zc));
+          const float zf = fmaf(za, pos(za) ? xh : xl, fmaf(zb, pos(zb) ? yh : yl, zc));
+          dn[qi] = zn <= 1.0f ? __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f)) : NONE;
+          const float n0 = fmaf(e0a, pos(e0a) ? xl : xh, fmaf(e0b, pos(e0b) ? yl : yh, e0c));
+          const float n1 = fmaf(e1a, pos(e1a) ? xl : xh, fmaf(e1b, pos(e1b) ? yl : yh, e1c));
+          const float n2 = fmaf(e2a, pos(e2a) ? xl : xh, fmaf(e2b, pos(e2b) ? yl : yh, e2c));
+          const float rwn = fmaf(wa, pos(wa) ? xl : xh, fmaf(wb, pos(wb) ? yl : yh, wc));
+          const bool cov = (n0 > 0.0f) & (n1 > 0.0f) & (n2 > 0.0f) & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) &
+                           (x0 <= rx0) & (x1 >= rx0 + 31) & (y0 <= ry0) & (y1 >= ry0 + 31) &
+                           ((c4.y & RASTER_MASKED_INTERIOR) == 0u);
+          myqb |= (cov && !no_cover) ? (16u << qi) : 0u;  // no_cover: test hook
+        }
+        dnq0 = dn[0], dnq1 = dn[1], dnq2 = dn[2], dnq3 = dn[3];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  };
+  if (single && count != 0u) gather(0u);
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
     const int qx0 = tx0 + (q & 1) * 32, qy0 = ty0 + (q >> 1) * 32;  // this quadrant
     if (qx0 >= width || qy0 >= height) continue;                    // entirely outside the frame (partial tiles)
     const int bx = qx0 + lx, by = qy0 + ly;                         // this lane's 4x4 block
     const float pxlo = (float)bx + 0.5f, pxhi = (float)bx + 3.5f, pylo = (float)by + 0.5f, pyhi = (float)by + 3.5f;
+    if (single && n != 0u) {
+      // Shortcut for the commonest quadrant of all: its nearest entry covers it entirely and every other entry of the
+      // (complete, single-batch) list lies strictly behind that entry's FARTHEST depth over the quadrant -- the entry
+      // wins all 1024 pixels without a compare (extremes of the computed depth sit at corners; strictness rules out
+      // ties).  Nothing is initialised for such a quadrant; the visibility words are one broadcast value.
+      const uint32_t dnq_s = q == 0 ? dnq0 : (q == 1 ? dnq1 : (q == 2 ? dnq2 : dnq3));
+      const unsigned long long touch_s = __ballot(((myqb >> q) & 1u) != 0u);
+      const unsigned long long cover_s = __ballot(((myqb >> (4 + q)) & 1u) != 0u);
+      if (touch_s != 0ull) {
+        const uint32_t s0 = (uint32_t)__builtin_ctzll(touch_s);
+        if ((cover_s >> s0) & 1ull) {
+          const float za0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpa, (int)s0)),
+                      zb0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpb, (int)s0)),
+                      zc0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpc, (int)s0));
+          const float xl = (float)qx0 + 0.5f, xh = (float)qx0 + 31.5f, yl = (float)qy0 + 0.5f, yh = (float)qy0 + 31.5f;
+          const float zf0 = fmaf(za0, pos(za0) ? xh : xl, fmaf(zb0, pos(zb0) ? yh : yl, zc0));  // in [0, 1]: the entry covers
+          const uint32_t df0 = __float2uint_rz(fmaf(zf0, 16777215.0f, 0.5f));
+          if ((__ballot(dnq_s <= df0) & touch_s & ~(1ull << s0)) == 0ull) {
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)myrec, (int)s0);
+            if (STATS) st[0] += (unsigned long long)__popcll(touch_s), st[9]++;
+            if (bx < width) {
+              const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
+              const uint32_t p0 = prim_out ? (prec[r0].r.flags & 0xFFFFFFu) : 0u;
+#pragma unroll
+              for (int ry = 0; ry < 4; ry++) {
+                if (by + ry < height) {
+                  const size_t o = o0 + (size_t)(ry * width);
+                  if (vis16)
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) = make_uint2(r0 | (r0 << 16), r0 | (r0 << 16));
+                  else
+                    *reinterpret_cast<uint4 *>(vis + o) = make_uint4(r0, r0, r0, r0);
+                  if (prim_out) *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p0, p0, p0, p0);
+                }
+              }
+            }
+            continue;
+          }
+        }
+      }
+    }
     uint32_t best_d[16], best_r[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -279,83 +399,7 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
     uint32_t lane_far = NONE;  // max of best_d: the farthest depth this lane still holds
 #pragma unroll 1
     for (uint32_t base = 0; base < count; base += 64u) {
-      if (!single || q == 0) {
-        // ---- candidates: one per lane ----------------------------------------------------------------
-        const uint32_t i = base + (uint32_t)lane;
-        uint32_t cand = 0, qb = 0;
-        if (i < count) {
-          if (binned) {
-            const uint32_t e = pent[i];
-            cand = e & 0x0FFFFFFFu;
-            qb = e >> 28;  // exact quadrant tests done by the binning kernel
-          } else {
-            // pose without complete bins: every visible triangle is a candidate; bbox, then the exact quadrant tests
-            const uint4 bb = psorted[i];  // (bb0, bb1, record index, depth bucket), near to far
-            cand = bb.z;
-            const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
-            if (x0 <= tx0 + 63 && x1 >= tx0 && y0 <= ty0 + 63 && y1 >= ty0) {
-              const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[cand]);
-              qb = tile_quadrant_mask(rp[0], rp[1], rp[2], x0, y0, x1, y1, tx0, ty0);
-            }
-          }
-        }
-
-        const unsigned long long rm = __ballot(qb != 0u);
-        n = (uint32_t)__popcll(rm);
-        if (n != 0u) {
-          // rank of my entry among the relevant ones (record index = depth rank; the lists are near-sorted already)
-          uint32_t rank = 0;
-          for (unsigned long long m = rm; m; m &= m - 1ull) {
-            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(m));
-            rank += kj < cand ? 1u : 0u;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier readers of myq / wrec are done
-          if (qb != 0u) myq[rank] = cand | (qb << 28);
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          // ---- records: lane s gathers entry s -------------------------------------------------------
-          const bool have = (uint32_t)lane < n;
-          myrec = 0u, myqb = 0u, zpa = zpb = zpc = 0u, dnq0 = dnq1 = dnq2 = dnq3 = NONE;
-          if (have) {
-            const uint32_t e = myq[lane];
-            myrec = e & 0x0FFFFFFFu;
-            myqb = e >> 28;
-            const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[myrec]);
-            const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3];
-            const uint2 c4 = *reinterpret_cast<const uint2 *>(rp + 4);
-            uint4 *mine = wrec[wave][lane];
-            mine[0] = c0, mine[1] = c1, mine[2] = c3, mine[3] = make_uint4(c2.x, c4.x, c4.y, 0u);
-            zpa = c2.y, zpb = c2.z, zpc = c2.w;
-            // per quadrant: nearest depth of my entry's plane over it as d24 (none if beyond far), and whether my
-            // entry covers it entirely -- the smallest computed value of each edge function and of 1/w and the
-            // extremes of the depth over the quadrant sit at corners (fmaf is monotone in each argument)
-            const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
-                        e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
-                        e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x);
-            const float za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
-            const float wa = __uint_as_float(c3.x), wb = __uint_as_float(c3.y), wc = __uint_as_float(c3.z);
-            const int x0 = (int)(c3.w & 0xFFFFu), y0 = (int)(c3.w >> 16), x1 = (int)(c4.x & 0xFFFFu), y1 = (int)(c4.x >> 16);
-            uint32_t dn[4];
-#pragma unroll
-            for (int qi = 0; qi < 4; qi++) {
-              const int rx0 = tx0 + (qi & 1) * 32, ry0 = ty0 + (qi >> 1) * 32;
-              const float xl = (float)rx0 + 0.5f, xh = (float)rx0 + 31.5f, yl = (float)ry0 + 0.5f, yh = (float)ry0 + 31.5f;
-              const float zn = fmaf(za, pos(za) ? xl : xh, fmaf(zb, pos(zb) ? yl : yh, zc));
-              const float zf = fmaf(za, pos(za) ? xh : xl, fmaf(zb, pos(zb) ? yh : yl, zc));
-              dn[qi] = zn <= 1.0f ? __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f)) : NONE;
-              const float n0 = fmaf(e0a, pos(e0a) ? xl : xh, fmaf(e0b, pos(e0b) ? yl : yh, e0c));
-              const float n1 = fmaf(e1a, pos(e1a) ? xl : xh, fmaf(e1b, pos(e1b) ? yl : yh, e1c));
-              const float n2 = fmaf(e2a, pos(e2a) ? xl : xh, fmaf(e2b, pos(e2b) ? yl : yh, e2c));
-              const float rwn = fmaf(wa, pos(wa) ? xl : xh, fmaf(wb, pos(wb) ? yl : yh, wc));
-              const bool cov = (n0 > 0.0f) & (n1 > 0.0f) & (n2 > 0.0f) & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) &
-                               (x0 <= rx0) & (x1 >= rx0 + 31) & (y0 <= ry0) & (y1 >= ry0 + 31) &
-                               ((c4.y & RASTER_MASKED_INTERIOR) == 0u);
-              myqb |= (cov && !no_cover) ? (16u << qi) : 0u;  // no_cover: test hook
-            }
-            dnq0 = dn[0], dnq1 = dn[1], dnq2 = dn[2], dnq3 = dn[3];
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-      }
+      if (!single) gather(base);
       if (n == 0u) continue;
       // ---- walk: the entries that touch this quadrant, near to far -------------------------------------------
       const uint32_t dnq = q == 0 ? dnq0 : (q == 1 ? dnq1 : (q == 2 ? dnq2 : dnq3));
@@ -364,27 +408,6 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
       // beyond the farthest depth ANY lane still holds: all entries are tested at once against that wave-wide maximum,
       // again whenever a body has brought some lane's depths nearer.
       const unsigned long long touch = __ballot(((myqb >> q) & 1u) != 0u);
-      if (single && touch != 0ull) {
-        // Shortcut for the commonest quadrant of all: its nearest entry covers it entirely and every other entry of the
-        // (complete, single-batch) list lies strictly behind that entry's FARTHEST depth over the quadrant -- the entry
-        // wins all 1024 pixels without a compare (extremes of the computed depth sit at corners; strictness rules out ties).
-        const uint32_t s0 = (uint32_t)__builtin_ctzll(touch);
-        if ((qcm >> s0) & 1ull) {
-          const float za0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpa, (int)s0)),
-                      zb0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpb, (int)s0)),
-                      zc0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpc, (int)s0));
-          const float xl = (float)qx0 + 0.5f, xh = (float)qx0 + 31.5f, yl = (float)qy0 + 0.5f, yh = (float)qy0 + 31.5f;
-          const float zf0 = fmaf(za0, pos(za0) ? xh : xl, fmaf(zb0, pos(zb0) ? yh : yl, zc0));  // in [0, 1]: the entry covers
-          const uint32_t df0 = __float2uint_rz(fmaf(zf0, 16777215.0f, 0.5f));
-          if ((__ballot(dnq <= df0) & touch & ~(1ull << s0)) == 0ull) {
-            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)myrec, (int)s0);
-#pragma unroll
-            for (int k = 0; k < 16; k++) best_r[k] = r0;
-            if (STATS) st[0] += (unsigned long long)__popcll(touch), st[9]++;
-            continue;  // (the only batch: on to the visibility words)
-          }
-        }
-      }
       uint32_t wave_far = wave_max_u32(lane_far);
       unsigned long long wm = touch & __ballot(dnq <= wave_far);
       if (STATS) st[0] += (unsigned long long)__popcll(touch), st[15] += (unsigned long long)__popcll(touch & ~wm);
