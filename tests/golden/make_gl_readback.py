@@ -5,6 +5,8 @@
   * the 27 golden poses (tests/golden/poses.npy: 9 levels x {spawn view = BASELINE config 2's pose at 320x200, two
     seeded views, the third at time 1.7 s with its own light table}),
   * three frames with moving objects (per-object u_modelview, engine/src/renderer.rs:120-132),
+  * twelve targeted views of E1M1: under open sky looking up, close to decorations, along scrolling / animated
+    textures at non-zero times,
   * pose 0 of the benchmark sweep at 1920x1080 (BASELINE config 3's frame size),
 
 each with the auxiliary winner-id pass, and the mismatch census of the ORACLE's frame against them
@@ -55,6 +57,47 @@ def frame_list():
     return out
 
 
+def targeted_frames(levels):
+    """views the golden poses do not guarantee: under open sky looking up (sky.frag's mirrored / tiled bands), close to
+    decorations (sprite.vert / sprite.frag), and along scrolling / animated textures at non-zero times."""
+    from util import reference_projection, view_matrix
+    out = []
+    lv = levels(0)
+    rng = np.random.RandomState(3)
+    sky_verts = np.asarray(lv.sky_vertices, np.float32).reshape(-1, 3)
+    for i in range(4):
+        c = sky_verts[rng.randint(len(sky_verts))]
+        eye = np.array([c[0] + rng.uniform(-0.5, 0.5), 0.45 + rng.uniform(0, 0.3), c[2] + rng.uniform(-0.5, 0.5)])
+        pose = np.zeros(33, np.float32)
+        pose[:16], pose[16:32] = view_matrix(eye, rng.uniform(0, 2 * np.pi), rng.uniform(0.3, 1.3)), reference_projection(320, 200)
+        out.append(('L0_sky%d' % i, 0, 320, 200, pose, None))
+    dv = lv.decor_vertices
+    for k, q in enumerate(range(0, min(len(dv) // 4, 8), 2)):
+        c = dv['a_pos'][4 * q:4 * q + 4].mean(0)
+        ang = (0.3, 2.4, 4.5, 1.1)[k % 4]
+        eye = c + np.array([np.sin(ang) * 1.3, 0.1, np.cos(ang) * 1.3])
+        d = c - eye
+        pose = np.zeros(33, np.float32)
+        pose[:16], pose[16:32] = view_matrix(eye, np.arctan2(-d[0], -d[2]), 0.05), reference_projection(320, 200)
+        pose[32] = (0.0, 0.4, 2.9, 11.3)[k % 4]   # decor animation frames (sprite.vert:25-37)
+        out.append(('L0_decor%d' % k, 0, 320, 200, pose, None))
+    # scrolling walls (special 0x30, visitor.rs:922) and animated flats / walls at several times
+    sv = lv.static_vertices
+    tri = sv[np.asarray(lv.static_indices).reshape(-1, 3)]
+    moving = np.nonzero((tri['a_scroll_rate'][:, 2] != 0) | (tri['a_num_frames'][:, 2] > 1))[0]
+    for k in range(4):
+        t = tri[moving[rng.randint(len(moving))]]
+        c = t['a_pos'].mean(0)
+        ang = rng.uniform(0, 2 * np.pi)
+        eye = c + np.array([np.sin(ang) * 1.0, 0.2, np.cos(ang) * 1.0])
+        d = c - eye
+        pose = np.zeros(33, np.float32)
+        pose[:16], pose[16:32] = view_matrix(eye, np.arctan2(-d[0], -d[2]), -0.1), reference_projection(320, 200)
+        pose[32] = (0.7, 3.3, 9.1, 27.5)[k]
+        out.append(('L0_anim%d' % k, 0, 320, 200, pose, None))
+    return out
+
+
 def bench_pose(width, height):
     """pose 0 of the benchmark sweep of E1M1 (rust-doom_amd/sharding.py: pose_sweep)"""
     import importlib
@@ -72,11 +115,14 @@ def main():
     frames = frame_list()
     frames.append(('L0_bench0_1080p', 0, 1920, 1080, bench_pose(1920, 1080), None))
     levels, gls, oracles = {}, {}, {}
+    levels[0] = wad_oracle.build_level(wad, META_PATH, 0)
+    frames += targeted_frames(lambda i: levels[i])
     arrays, census = {}, {'swiftshader': gl_readback.gl().version, 'subpixel_bits': gl_readback.gl().subpixel_bits,
                           'jitter_px': gl_census.JITTER, 'frames': {}}
     for key, index, w, h, pose, obj_seed in frames:
         if index not in levels:
             levels[index] = wad_oracle.build_level(wad, META_PATH, index)
+        if index not in gls:
             gls[index] = gl_readback.GLReference(levels[index])
             oracles[index] = raster.RasterOracle(levels[index])
         lv = levels[index]
