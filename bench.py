@@ -61,6 +61,8 @@ def parse_args(argv=None):
     ap.add_argument('--big', action='store_true', help='the 10x-E1M1 synthetic level (stand-in for DOOM2 MAP29)')
     ap.add_argument('--iwad', default=None)
     ap.add_argument('--metadata', default=None)
+    ap.add_argument('--streams', type=int, default=1,
+                    help='experiment: S sub-batches on S HIP streams (per-kernel times then overlap; default 1)')
     ap.add_argument('--cpu-sample', type=int, default=512, help='poses rendered by the CPU oracle (0 = skip)')
     ap.add_argument('--dry-run', action='store_true',
                     help='everything but the device work (rank launch, pose partition, barrier): for hosts without a GPU; prints no value')
@@ -94,7 +96,7 @@ def kernel_source_digest():
 def workload_key(args, levels):
     return '%s|levels=%s|%dx%d|poses=%d|tv=%d' % ('big' if args.big else (os.path.basename(args.iwad) if args.iwad else 'synth'),
                                                    ','.join(map(str, levels)), args.width, args.height, args.poses,
-                                                   int(args.time_varying))
+                                                   int(args.time_varying)) + ('|streams=%d' % args.streams if args.streams > 1 else '')
 
 
 def spawn_ranks(args):
@@ -183,15 +185,21 @@ def main():
         built = wad.build_level(index, gpu_tessellation=True)   # SSECTOR -> polygon, SEG -> quad kernels
         t_build += time.perf_counter() - t0
         level = rd.DeviceLevel(built)                            # level arrays now resident in HBM
-        batch = rd.Batch(level, args.width, args.height, max(n_mine, 1))
-        poses = sharding.pose_sweep(rd, built, n_mine, args.width, args.height, first=lo)
-        if args.time_varying:
-            times = (np.arange(lo, hi) / 35.0).astype(np.float32)
-            poses['time'] = times
-            lights = np.stack([built.lights_at(float(t)) for t in times]) if n_mine else np.zeros((0, 256), np.uint8)
-        else:
-            lights = built.lights_at(0.0)
-        work.append((built, level, batch, poses, lights))
+        # --streams S (experiment, default 1): the rank's poses as S sub-batches on S HIP streams, so that one
+        # sub-batch's rasteriser overlaps another's fragment kernel
+        for part in range(args.streams):
+            plo, phi = (lo + sharding.shard_range(n_mine, part, args.streams)[0],
+                        lo + sharding.shard_range(n_mine, part, args.streams)[1])
+            batch = rd.Batch(level, args.width, args.height, max(phi - plo, 1))
+            poses = sharding.pose_sweep(rd, built, phi - plo, args.width, args.height, first=plo)
+            if args.time_varying:
+                times = (np.arange(plo, phi) / 35.0).astype(np.float32)
+                poses['time'] = times
+                lights = np.stack([built.lights_at(float(t)) for t in times]) if phi > plo else np.zeros((0, 256), np.uint8)
+            else:
+                lights = built.lights_at(0.0)
+            stream = torch.cuda.Stream().cuda_stream if args.streams > 1 else None
+            work.append((built, level, batch, poses, lights, stream))
 
     def barrier():
         torch.cuda.synchronize()
@@ -203,7 +211,7 @@ def main():
     # step i); the hipEvents around every kernel of every timed step stay pending on the render stream and are read
     # after the closing barrier (at most 64 renders per batch may be pending: collected in between if K is larger).
     def collect(acc):
-        for _built, _level, batch, _poses, _lights in work:
+        for _built, _level, batch, _poses, _lights, _stream in work:
             t = batch.collect_timings()
             if acc is not None and t['renders']:
                 for k in ('setup_ms', 'raster_ms', 'fragment_ms'):
@@ -212,9 +220,9 @@ def main():
                 acc['fixup_pixels'] = acc.get('fixup_pixels', 0) + t['fixup_pixels'] * t['renders']
 
     def step(i):
-        for _built, _level, batch, poses, lights in work:
-            if n_mine:
-                batch.render_profiled(poses, lights)
+        for _built, _level, batch, poses, lights, stream in work:
+            if len(poses):
+                batch.render_profiled(poses, lights, stream=stream)
         if i % 60 == 59:
             return True
         return False
@@ -254,10 +262,10 @@ def main():
         cpu = None
         if args.cpu_sample > 0 and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             from oracle import raster
-            built, _level, _batch, poses, lights = work[0]
+            built, _level, _batch, poses, lights, _stream = work[0]
             ro = raster.RasterOracle(built.arrays())
             cores = os.cpu_count() or 1
-            n = min(args.cpu_sample, n_mine)
+            n = min(args.cpu_sample, len(poses))
             sample = np.zeros((n, 33), np.float32)
             sample[:, :16] = poses['modelview'][:n]
             sample[:, 16:32] = poses['projection'][:n]
@@ -293,6 +301,7 @@ def main():
                        'alpha_leak_fixup_pixels_per_step': acc.get('fixup_pixels', 0) // max(1, args.steps),
                        'kernels_ms': {k[:-3]: round(acc[k] / args.steps, 3) for k in ('setup_ms', 'raster_ms', 'fragment_ms')},
                        'parallelism': 'pose-sharded x%d, no collective' % world,
+                       'streams': args.streams,
                        'workload_key': workload_key(args, levels), 'kernel_sources': kernel_source_digest()},
             'roofline': {'bound': 'hbm', 'kernel': 'fragment_kernel', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),

@@ -45,6 +45,9 @@ namespace {
 __device__ unsigned long long g_frag_stats[16];
 #endif
 constexpr int FRAG_CHUNK = 16;
+typedef uint32_t TexelWord __attribute__((aligned(2)));
+// six waves per SIMD: at most 80 VGPRs
+#define FRAG_OCCUPANCY __attribute__((amdgpu_waves_per_eu(6, 8)))
 constexpr int FRAG_WLIST = 160;  // per-wave list of unfinished quads: at most 15 carried over + 64 x 2 new
 
 __device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const uint8_t *cmap, float px, float py,
@@ -101,7 +104,7 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
 
 template <int NQ, int DBG, bool VIS16>  // NQ: adjacent quads per lane (1 or 2; the frame width is a multiple of 4 NQ);
                                         // DBG: timing experiments only; VIS16: 16-bit visibility words (0xFFFF = none)
-__global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+__global__ __launch_bounds__(256) FRAG_OCCUPANCY void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
                                                        const uint32_t *__restrict__ vis, uint32_t n_poses,
                                                        uint32_t chunks_per_pose, uint32_t chunk_iters,
@@ -176,35 +179,42 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
   // patch of texture space -- a few cache lines per load instruction instead of one per lane on floors and ceilings.
   const uint32_t units_per_row = quads_per_row / (uint32_t)NQ;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // the lane's share of col / row / quad index is loop-invariant; the block's share is scalar arithmetic
+  const uint32_t lane_col = lane & ((1u << bw_log2) - 1u), lane_row = lane >> bw_log2;
+  uint32_t lane_q = lane_row * quads_per_row + lane_col * (uint32_t)NQ;
+  asm("" : "+v"(lane_q));  // (opaque: otherwise the product with the row is re-derived inside the loop)
+  // byte offsets from the pose's visibility words / framebuffer fit 32 bits (quads_per_pose < 2^24): one VGPR each
+  const char *pvis_bytes = VIS16 ? reinterpret_cast<const char *>(pvis16) : reinterpret_cast<const char *>(pvis32);
+  char *pfb_bytes = reinterpret_cast<char *>(pfb);
   for (uint32_t it = 0; it < chunk_iters; it++) {
     const uint32_t wb = (chunk * chunk_iters + it) * 4u + wave;
     if (wb >= wblocks_per_pose) break;  // wave-uniform: past the end of the frame
     const uint32_t wby = wb / wblocks_per_row, wbx = wb - wby * wblocks_per_row;
-    const uint32_t col = (wbx << bw_log2) + (lane & ((1u << bw_log2) - 1u)), row = (wby << (6u - bw_log2)) + (lane >> bw_log2);
+    const uint32_t col = (wbx << bw_log2) + lane_col, row = (wby << (6u - bw_log2)) + lane_row;
     const bool valid = (col < units_per_row) & (row < (uint32_t)height);
     const uint32_t qx = col * (uint32_t)NQ;
-    const uint32_t q0 = row * quads_per_row + qx;
+    const uint32_t q0 = ((wby << (6u - bw_log2)) * quads_per_row + (wbx << bw_log2) * (uint32_t)NQ) + lane_q;
     // visibility words of my NPX pixels: all the same?  (compared as loaded, two 16-bit words at a time; a lane outside
     // the frame reads unit 0 and is treated as background -- no divergent branch, no boolean phi)
-    const size_t q0l = valid ? (size_t)q0 : (size_t)0;
+    const uint32_t q0l = valid ? q0 : 0u;
     uint32_t id0;
     bool uniform;
     if (VIS16) {
       if (NQ == 2) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(pvis16 + q0l * 4u);
+        const uint4 v = *reinterpret_cast<const uint4 *>(pvis_bytes + q0l * 8u);
         id0 = v.x & 0xFFFFu;
         uniform = (((v.x ^ __builtin_amdgcn_alignbit(v.x, v.x, 16)) | (v.x ^ v.y)) | ((v.y ^ v.z) | (v.z ^ v.w))) == 0u;
       } else {
-        const uint2 v = *reinterpret_cast<const uint2 *>(pvis16 + q0l * 4u);
+        const uint2 v = *reinterpret_cast<const uint2 *>(pvis_bytes + q0l * 8u);
         id0 = v.x & 0xFFFFu;
         uniform = ((v.x ^ __builtin_amdgcn_alignbit(v.x, v.x, 16)) | (v.x ^ v.y)) == 0u;
       }
     } else {
-      const uint4 v = *reinterpret_cast<const uint4 *>(pvis32 + q0l * 4u);
+      const uint4 v = *reinterpret_cast<const uint4 *>(pvis_bytes + q0l * 16u);
       id0 = v.x;
       uint32_t diff = (v.x ^ v.y) | (v.y ^ v.z) | (v.z ^ v.w);
       if (NQ == 2) {
-        const uint4 w = *reinterpret_cast<const uint4 *>(pvis32 + (q0l + 1u) * 4u);
+        const uint4 w = *reinterpret_cast<const uint4 *>(pvis_bytes + (q0l + 1u) * 16u);
         diff |= (w.x ^ id0) | (w.x ^ w.y) | (w.y ^ w.z) | (w.z ^ w.w);
       }
       uniform = diff == 0u;
@@ -216,114 +226,147 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
 #pragma unroll
     for (int q = 0; q < NQ; q++) out[q] = 0;
     if (uniform & (id0 == NONE_ID)) done = true;  // background (or past the end: nothing is stored)
-    if (uniform & (id0 != NONE_ID) & (debug_leak_mod == 0u)) {
+    // The packed body for a run that lies in ONE flat / wall triangle with SHADE_FAST.  ONE = the whole wave holds the
+    // same record (77 % of the waves of the 1080p E1M1 sweep): its words then arrive by scalar loads and are SGPR
+    // operands of the packed instructions -- no per-lane record loads, no register pairs to build for the splats.
+    auto fast_run = [&](auto one, const uint4 r0, const uint4 r1, const uint4 r2, const uint4 r3)
+                        __attribute__((always_inline)) {
+      constexpr bool ONE = decltype(one)::value;
+      const uint32_t flags = r3.z, tex = r3.w;
+      const float wa = __uint_as_float(r0.x), wb = __uint_as_float(r0.y), wc = __uint_as_float(r0.z),
+                  ua = __uint_as_float(r0.w), ub = __uint_as_float(r1.x), uc = __uint_as_float(r1.y),
+                  va = __uint_as_float(r1.z), vb = __uint_as_float(r1.w), vc = __uint_as_float(r2.x),
+                  atlas_u = __uint_as_float(r2.y), atlas_v = __uint_as_float(r2.z), size_x = __uint_as_float(r2.w),
+                  size_y = __uint_as_float(r3.x), light = __uint_as_float(r3.y);
+      const float py = (float)row + 0.5f;
+      const float px0 = (float)(qx * 4u) + 0.5f;
+      const float row_w = fmaf(wb, py, wc), row_u = fmaf(ub, py, uc), row_v = fmaf(vb, py, vc);
+      // F2 preparation: q0 = t * RN(1/size) equals the quotient exactly for a power-of-two size; for an integer
+      // size it is within |t/size| * 2^-23 of it, and the remainder test below certifies
+      // floor(q0) == floor(RN(t / size)) (else the run goes to the general body).
+      // (1 / 2^k is one integer subtraction on the exponent field; the reciprocal forms only run in waves that hold
+      // a record with an integer, non-power-of-two size)
+      const bool any_np2 = ONE ? (flags & SHADE_NP2) != 0u : __any((flags & SHADE_NP2) != 0u);
+      f32x2 inv_s = {__uint_as_float(0x7F000000u - __float_as_uint(size_x)), __uint_as_float(0x7F000000u - __float_as_uint(size_y))};
+      if (any_np2) inv_s = exact_rcp2(f32x2{size_x, size_y});
+      // F3 parameters: one u16 texel store, REPEAT = masks
+      const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
+      const uint32_t base2 = base * 2u;  // byte offsets < 2^27: one 32-bit VGPR offset from the uniform base pointer
+      const char *tb = reinterpret_cast<const char *>(lv.texels);
+      // Certificate for integer (non-power-of-two) tile sizes, evaluated only in waves that hold such a record
+      // (fastmath.hpp, mod_cert): with guard >= 2^-20 * max(|x|, y), guard <= r <= y - guard and |x| < 2^23 imply that
+      // no integer lies between x * RN(1/y) and RN(x / y) and that y * floor is exact.  One guard per run and axis:
+      // |x_k| = |n_k * w_k| <= max(|n_first|, |n_last|) * max(w_first, w_last) because the numerator plane n and, for
+      // rw > 0, w = 1/rw are monotone along the run (and rounding is monotone).  The run's guard is at least every
+      // pixel's own guard, so passing here implies mod_cert() for each pixel -- the form the on-device self-test sweeps.
+      // Power-of-two axes always pass.
+      const bool p2x = (flags & SHADE_POW2_X) != 0u, p2y = (flags & SHADE_POW2_Y) != 0u;
+      bool mod_ok = true;
+      float lox = 0.0f, hix = 0.0f, loy = 0.0f, hiy = 0.0f;
+      if (any_np2) {
+        const float pxl = px0 + (float)(NPX - 1);
+        const f32x2 w_ends = exact_rcp2(f32x2{fmaf(wa, px0, row_w), fmaf(wa, pxl, row_w)});
+        const float w_hi = fmaxf(w_ends.x, w_ends.y);
+        const float bu = fmaxf(fabsf(fmaf(ua, px0, row_u)), fabsf(fmaf(ua, pxl, row_u))) * w_hi;
+        const float bv = fmaxf(fabsf(fmaf(va, px0, row_v)), fabsf(fmaf(va, pxl, row_v))) * w_hi;
+        lox = fmaxf(bu, size_x) * 0x1p-20f, hix = size_x - lox;
+        loy = fmaxf(bv, size_y) * 0x1p-20f, hiy = size_y - loy;
+        mod_ok = (p2x | (bu < 0x1p23f)) & (p2y | (bv < 0x1p23f));
+      }
+      f32x2 ww[NP];
+      uint32_t texel[NPX], any_texel = 0;
+      float rw_first = 0.0f, rw_last = 0.0f;
+#pragma unroll
+      for (int p = 0; p < NP; p++) {  // one pair of pixels at a time, straight through to its two texel loads
+        const f32x2 px = {px0 + (float)(2 * p), px0 + (float)(2 * p + 1)};
+        const f32x2 rw = pk_fma(splat(wa), px, splat(row_w));  // F1
+        if (p == 0) rw_first = rw.x;
+        if (p == NP - 1) rw_last = rw.y;
+        ww[p] = exact_rcp2(rw);
+        const f32x2 tu = pk_fma(splat(ua), px, splat(row_u)) * ww[p];
+        const f32x2 tv = pk_fma(splat(va), px, splat(row_v)) * ww[p];
+        f32x2 fq = tu * splat(inv_s.x);  // F2: mod(t, size) = t - size * floor(t / size)
+        fq = f32x2{floorf(fq.x), floorf(fq.y)};
+        const f32x2 rx = pk_fma(splat(-size_x), fq, tu);
+        f32x2 fh = tv * splat(inv_s.y);
+        fh = f32x2{floorf(fh.x), floorf(fh.y)};
+        const f32x2 ry = pk_fma(splat(-size_y), fh, tv);
+        if (any_np2)
+          mod_ok = mod_ok & (p2x | ((rx.x >= lox) & (rx.x <= hix) & (rx.y >= lox) & (rx.y <= hix))) &
+                   (p2y | ((ry.x >= loy) & (ry.x <= hiy) & (ry.y >= loy) & (ry.y <= hiy)));
+        const f32x2 ux = rx + splat(atlas_u), uy = ry + splat(atlas_v);  // F3
+        const uint32_t o0 = (((uint32_t)cvt_floor_i32(uy.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.x) & wm);
+        const uint32_t o1 = (((uint32_t)cvt_floor_i32(uy.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.y) & wm);
+        // (a 32-bit load at the texel's 2-byte-aligned address: bits 0..7 = palette index and bit 15 = transparent are
+        // all that is read from it, the upper half is the next texel -- the array ends with a padding texel.  A 16-bit
+        // load would be zero-extended again wherever it is used in another basic block: eight more instructions per run)
+        texel[2 * p] = (DBG & 2) ? (o0 & 255u) : *reinterpret_cast<const TexelWord *>(tb + (o0 * 2u + base2));
+        texel[2 * p + 1] = (DBG & 2) ? (o1 & 255u) : *reinterpret_cast<const TexelWord *>(tb + (o1 * 2u + base2));
+      }
+      // rw is monotone along the run: both ends inside the verified range of the exact reciprocal forms
+      // (one unsigned compare per end: the bit patterns of [2^-100, 2^100] are the integers [0x0D800000, 0x71800000];
+      // negative numbers and NaNs land above the interval)
+      const uint32_t off_first = __float_as_uint(rw_first) - 0x0D800000u, off_last = __float_as_uint(rw_last) - 0x0D800000u;
+      const bool in_range = max(off_first, off_last) <= 0x71800000u - 0x0D800000u;
+#pragma unroll
+      for (int k = 0; k < NPX; k++) any_texel |= texel[k];
+      // F4, F5 at the two end pixels; the pixels between them only when the ends disagree
+      auto rows_of = [&](f32x2 dist) {
+        const f32x2 dterm = splat(1.0f) - exact_div09_2(dist + splat(0.9f));
+        const f32x2 lgt = splat(light * 2.0f) - f32x2{fminf(1.0f, dterm.x), fminf(1.0f, dterm.y)};
+        const f32x2 tt = (splat(1.0f) - lgt) * splat(32.0f);
+        return f32x2{fminf(fmaxf(floorf(tt.x), 0.0f), 31.0f), fminf(fmaxf(floorf(tt.y), 0.0f), 31.0f)};
+      };
+      const f32x2 rf_ends = rows_of(f32x2{ww[0].x, ww[NP - 1].y});
+      uint32_t ci[NPX];  // COLORMAP index = row * 256 + texel
+      if (rf_ends.x == rf_ends.y) {
+        const uint32_t r8 = (uint32_t)(int)rf_ends.x << 8;
+#pragma unroll
+        for (int k = 0; k < NPX; k++) ci[k] = r8 | (texel[k] & 0xFFu);
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+          const f32x2 rows = rows_of(ww[p]);
+          ci[2 * p] = ((uint32_t)(int)rows.x << 8) | (texel[2 * p] & 0xFFu);
+          ci[2 * p + 1] = ((uint32_t)(int)rows.y << 8) | (texel[2 * p + 1] & 0xFFu);
+        }
+      }
+      const bool opaque = (any_texel & 0x8000u) == 0u;
+#ifdef RDOOM_FRAG_STATS
+      if (!in_range) atomicAdd(&g_frag_stats[11], 1ull);
+      if (!mod_ok) atomicAdd(&g_frag_stats[12], 1ull);
+      if (!opaque) atomicAdd(&g_frag_stats[13], 1ull);
+#endif
+      if (in_range & mod_ok & opaque) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+          const uint32_t c0 = cmap[ci[2 * p]], c1 = cmap[ci[2 * p + 1]];
+          out[p >> 1] |= (c0 | (c1 << 8)) << (16 * (p & 1));
+        }
+        done = true;
+      }
+    };
+    // wave-uniform record?  (the broadcast is an unconditional initialiser, see DESIGN 5 on v_readlane under branches)
+    const uint32_t id_one = (uint32_t)__builtin_amdgcn_readfirstlane((int)id0);
+    const bool wave_one = __all(uniform & valid & (id0 == id_one)) & (id_one != NONE_ID) & (debug_leak_mod == 0u);
+    bool took_one = false;
+    if (wave_one) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[id_one].s);
+      const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+      asm volatile("" ::"s"(r0.x), "s"(r1.x), "s"(r2.x));  // (all four scalar loads in flight before the flag is examined)
+      if (r3.z & SHADE_FAST) {
+        fast_run(std::true_type{}, r0, r1, r2, r3);
+        took_one = true;
+      }
+    }
+    if (!took_one & uniform & (id0 != NONE_ID) & (debug_leak_mod == 0u)) {
       const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[id0].s);
       const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-      const uint32_t flags = r3.z, tex = r3.w;
+      const uint32_t flags = r3.z;
       // (all four loads are issued before the flag is examined: one memory latency, not two)
       asm volatile("" ::"v"(r0.x), "v"(r1.x), "v"(r2.x));
       if (flags & SHADE_FAST) {
-        const float wa = __uint_as_float(r0.x), wb = __uint_as_float(r0.y), wc = __uint_as_float(r0.z),
-                    ua = __uint_as_float(r0.w), ub = __uint_as_float(r1.x), uc = __uint_as_float(r1.y),
-                    va = __uint_as_float(r1.z), vb = __uint_as_float(r1.w), vc = __uint_as_float(r2.x),
-                    atlas_u = __uint_as_float(r2.y), atlas_v = __uint_as_float(r2.z), size_x = __uint_as_float(r2.w),
-                    size_y = __uint_as_float(r3.x), light = __uint_as_float(r3.y);
-        const float py = (float)row + 0.5f;
-        const float px0 = (float)(qx * 4u) + 0.5f;
-        const float row_w = fmaf(wb, py, wc), row_u = fmaf(ub, py, uc), row_v = fmaf(vb, py, vc);
-        // F2 preparation: q0 = t * RN(1/size) equals the quotient exactly for a power-of-two size; for an integer
-        // size it is within |t/size| * 2^-23 of it, and the remainder test below certifies
-        // floor(q0) == floor(RN(t / size)) (else the run goes to the general body).
-        // (1 / 2^k is one integer subtraction on the exponent field; the reciprocal forms only run in waves that hold
-        // a record with an integer, non-power-of-two size)
-        const bool any_np2 = __any((flags & SHADE_NP2) != 0u);
-        f32x2 inv_s = {__uint_as_float(0x7F000000u - __float_as_uint(size_x)), __uint_as_float(0x7F000000u - __float_as_uint(size_y))};
-        if (any_np2) inv_s = exact_rcp2(f32x2{size_x, size_y});
-        // F3 parameters: one u16 texel store, REPEAT = masks
-        const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
-        const uint32_t base2 = base * 2u;  // byte offsets < 2^27: one 32-bit VGPR offset from the uniform base pointer
-        const char *tb = reinterpret_cast<const char *>(lv.texels);
-        // Certificate for integer (non-power-of-two) tile sizes, evaluated only in waves that hold such a record
-        // (fastmath.hpp, mod_cert): with guard >= 2^-20 * max(|x|, y), guard <= r <= y - guard and |x| < 2^23 imply that
-        // no integer lies between x * RN(1/y) and RN(x / y) and that y * floor is exact.  One guard per run and axis:
-        // |x_k| = |n_k * w_k| <= max(|n_first|, |n_last|) * max(w_first, w_last) because the numerator plane n and, for
-        // rw > 0, w = 1/rw are monotone along the run (and rounding is monotone).  The run's guard is at least every
-        // pixel's own guard, so passing here implies mod_cert() for each pixel -- the form the on-device self-test sweeps.
-        // Power-of-two axes always pass.
-        const bool p2x = (flags & SHADE_POW2_X) != 0u, p2y = (flags & SHADE_POW2_Y) != 0u;
-        bool mod_ok = true;
-        float lox = 0.0f, hix = 0.0f, loy = 0.0f, hiy = 0.0f;
-        if (any_np2) {
-          const float pxl = px0 + (float)(NPX - 1);
-          const f32x2 w_ends = exact_rcp2(f32x2{fmaf(wa, px0, row_w), fmaf(wa, pxl, row_w)});
-          const float w_hi = fmaxf(w_ends.x, w_ends.y);
-          const float bu = fmaxf(fabsf(fmaf(ua, px0, row_u)), fabsf(fmaf(ua, pxl, row_u))) * w_hi;
-          const float bv = fmaxf(fabsf(fmaf(va, px0, row_v)), fabsf(fmaf(va, pxl, row_v))) * w_hi;
-          lox = fmaxf(bu, size_x) * 0x1p-20f, hix = size_x - lox;
-          loy = fmaxf(bv, size_y) * 0x1p-20f, hiy = size_y - loy;
-          mod_ok = (p2x | (bu < 0x1p23f)) & (p2y | (bv < 0x1p23f));
-        }
-        f32x2 ww[NP];
-        uint32_t texel[NPX], any_texel = 0;
-        float rw_first = 0.0f, rw_last = 0.0f;
-#pragma unroll
-        for (int p = 0; p < NP; p++) {  // one pair of pixels at a time, straight through to its two texel loads
-          const f32x2 px = {px0 + (float)(2 * p), px0 + (float)(2 * p + 1)};
-          const f32x2 rw = pk_fma(splat(wa), px, splat(row_w));  // F1
-          if (p == 0) rw_first = rw.x;
-          if (p == NP - 1) rw_last = rw.y;
-          ww[p] = exact_rcp2(rw);
-          const f32x2 tu = pk_fma(splat(ua), px, splat(row_u)) * ww[p];
-          const f32x2 tv = pk_fma(splat(va), px, splat(row_v)) * ww[p];
-          f32x2 fq = tu * splat(inv_s.x);  // F2: mod(t, size) = t - size * floor(t / size)
-          fq = f32x2{floorf(fq.x), floorf(fq.y)};
-          const f32x2 rx = pk_fma(splat(-size_x), fq, tu);
-          f32x2 fh = tv * splat(inv_s.y);
-          fh = f32x2{floorf(fh.x), floorf(fh.y)};
-          const f32x2 ry = pk_fma(splat(-size_y), fh, tv);
-          if (any_np2)
-            mod_ok = mod_ok & (p2x | ((rx.x >= lox) & (rx.x <= hix) & (rx.y >= lox) & (rx.y <= hix))) &
-                     (p2y | ((ry.x >= loy) & (ry.x <= hiy) & (ry.y >= loy) & (ry.y <= hiy)));
-          const f32x2 ux = rx + splat(atlas_u), uy = ry + splat(atlas_v);  // F3
-          const uint32_t o0 = (((uint32_t)cvt_floor_i32(uy.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.x) & wm);
-          const uint32_t o1 = (((uint32_t)cvt_floor_i32(uy.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.y) & wm);
-          texel[2 * p] = (DBG & 2) ? (o0 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o0 * 2u + base2));
-          texel[2 * p + 1] = (DBG & 2) ? (o1 & 255u) : *reinterpret_cast<const uint16_t *>(tb + (o1 * 2u + base2));
-        }
-        // rw is monotone along the run: both ends inside the verified range of the exact reciprocal forms
-        const bool in_range = (fminf(rw_first, rw_last) >= 0x1p-100f) & (fmaxf(rw_first, rw_last) <= 0x1p100f);
-#pragma unroll
-        for (int k = 0; k < NPX; k++) any_texel |= texel[k];
-        // F4, F5 at the two end pixels; the pixels between them only when the ends disagree
-        auto rows_of = [&](f32x2 dist) {
-          const f32x2 dterm = splat(1.0f) - exact_div09_2(dist + splat(0.9f));
-          const f32x2 lgt = splat(light * 2.0f) - f32x2{fminf(1.0f, dterm.x), fminf(1.0f, dterm.y)};
-          const f32x2 tt = (splat(1.0f) - lgt) * splat(32.0f);
-          return f32x2{fminf(fmaxf(floorf(tt.x), 0.0f), 31.0f), fminf(fmaxf(floorf(tt.y), 0.0f), 31.0f)};
-        };
-        const f32x2 rf_ends = rows_of(f32x2{ww[0].x, ww[NP - 1].y});
-        f32x2 rf[NP];
-#pragma unroll
-        for (int p = 0; p < NP; p++) rf[p] = splat(rf_ends.x);
-        if (rf_ends.x != rf_ends.y) {
-#pragma unroll
-          for (int p = 0; p < NP; p++) rf[p] = rows_of(ww[p]);
-        }
-        const bool opaque = (any_texel & 0x8000u) == 0u;
-#ifdef RDOOM_FRAG_STATS
-        if (!in_range) atomicAdd(&g_frag_stats[11], 1ull);
-        if (!mod_ok) atomicAdd(&g_frag_stats[12], 1ull);
-        if (!opaque) atomicAdd(&g_frag_stats[13], 1ull);
-#endif
-        if (in_range & mod_ok & opaque) {
-#pragma unroll
-          for (int p = 0; p < NP; p++) {
-            const uint32_t c0 = cmap[((uint32_t)(int)rf[p].x << 8) | (texel[2 * p] & 0xFFu)],
-                           c1 = cmap[((uint32_t)(int)rf[p].y << 8) | (texel[2 * p + 1] & 0xFFu)];
-            out[p >> 1] |= (c0 | (c1 << 8)) << (16 * (p & 1));
-          }
-          done = true;
-        }
+        fast_run(std::false_type{}, r0, r1, r2, r3);
       } else if ((flags & 3u) == RDOOM_KIND_SKY) {
         // a run of sky (sky.frag:12-26): the colour depends on the pixel and the pose only.  ndc_tab holds
         // p / (size / 2) - 1 for every column and row of the frame (computed once per batch with the same two
@@ -357,9 +400,9 @@ __global__ __launch_bounds__(256) void fragment_kernel(DeviceLevelView lv, const
     }
     if (done & valid) {
       if (NQ == 2)
-        *reinterpret_cast<uint2 *>(pfb + q0) = make_uint2(out[0], out[NQ - 1]);
+        *reinterpret_cast<uint2 *>(pfb_bytes + q0 * 4u) = make_uint2(out[0], out[NQ - 1]);
       else
-        pfb[q0] = out[0];
+        *reinterpret_cast<uint32_t *>(pfb_bytes + q0 * 4u) = out[0];
     }
 #ifdef RDOOM_FRAG_STATS
     if (valid) atomicAdd(&g_frag_stats[8], 1ull);
