@@ -230,8 +230,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return max(max(a, b), max(c, d));
 }
 
+#ifndef RDOOM_RASTER_WAVES
+#define RDOOM_RASTER_WAVES 4
+#endif
+constexpr uint32_t RASTER_WAVES = RDOOM_RASTER_WAVES;  // tiles (= waves) per workgroup
+
 template <bool STATS>
-__global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+__global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, 4) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                              const uint4 *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts, uint32_t cap,
                                                              uint32_t n_poses, int width, int height, int tiles_x,
@@ -242,14 +247,14 @@ __global__ __launch_bounds__(256, 4) void raster_wave_kernel(DeviceLevelView lv,
                                                              uint32_t *__restrict__ prim_out, uint32_t no_cover,
                                                              unsigned long long *__restrict__ stats) {
   unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  __shared__ uint32_t wq[4][64];
-  __shared__ uint4 wrec[4][64][4];  // per wave: 15 words of each of the 64 gathered raster records
+  __shared__ uint32_t wq[RASTER_WAVES][64];
+  __shared__ uint4 wrec[RASTER_WAVES][64][4];  // per wave: 15 words of each of the 64 gathered raster records
   const uint32_t b = blockIdx.x;
-  const uint32_t T = (uint32_t)(tiles_x * tiles_y), T4 = (T + 3u) >> 2;
+  const uint32_t T = (uint32_t)(tiles_x * tiles_y), T4 = (T + RASTER_WAVES - 1u) / RASTER_WAVES;
   const uint32_t g = b >> 3;
   const uint32_t pose = (g / T4) * 8u + (b & 7u);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave: an SGPR
-  const uint32_t tile = (g % T4) * 4u + (uint32_t)wave;
+  const uint32_t tile = (g % T4) * RASTER_WAVES + (uint32_t)wave;
   if (pose >= n_poses || tile >= T) return;
   const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE_W, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE_H;
   const int lx = (lane & 7) * 4, ly = (lane >> 3) * 4;  // this lane's 4x4 block inside a quadrant
@@ -510,7 +515,7 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
                            const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out) {
   const uint32_t n = n_poses;
-  const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)((tiles_x * tiles_y + 3) / 4);  // four tiles per workgroup
+  const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)((tiles_x * tiles_y + (int)RASTER_WAVES - 1) / (int)RASTER_WAVES);  // RASTER_WAVES tiles per workgroup
   if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
   const rdoom::DebugOptions &dbg = rdoom::debug_options();
   unsigned long long *d_stats = nullptr;
@@ -519,7 +524,7 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
     HIP_TRY(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
   }
   auto rk = dbg.raster_stats ? raster_wave_kernel<true> : raster_wave_kernel<false>;
-  hipLaunchKernelGGL(rk, dim3((uint32_t)nblocks), dim3(256), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
+  hipLaunchKernelGGL(rk, dim3((uint32_t)nblocks), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow, vis, vis16 ? 1u : 0u, prim_out, dbg.no_cover ? 1u : 0u,
                      d_stats);
   if (d_stats) {
