@@ -45,6 +45,10 @@ namespace {
 __device__ unsigned long long g_frag_stats[16];
 #endif
 constexpr int FRAG_CHUNK = 16;
+#ifndef RDOOM_FRAG_WAVES
+#define RDOOM_FRAG_WAVES 4
+#endif
+constexpr uint32_t FRAG_WAVES = RDOOM_FRAG_WAVES;  // waves per workgroup (they share the LDS copy of COLORMAP)
 typedef uint32_t TexelWord __attribute__((aligned(2)));
 // six waves per SIMD: at most 80 VGPRs
 #define FRAG_OCCUPANCY __attribute__((amdgpu_waves_per_eu(6, 8)))
@@ -104,7 +108,7 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
 
 template <int NQ, int DBG, bool VIS16>  // NQ: adjacent quads per lane (1 or 2; the frame width is a multiple of 4 NQ);
                                         // DBG: timing experiments only; VIS16: 16-bit visibility words (0xFFFF = none)
-__global__ __launch_bounds__(256) FRAG_OCCUPANCY void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+__global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
                                                        const uint32_t *__restrict__ vis, uint32_t n_poses,
                                                        uint32_t chunks_per_pose, uint32_t chunk_iters,
@@ -117,12 +121,12 @@ __global__ __launch_bounds__(256) FRAG_OCCUPANCY void fragment_kernel(DeviceLeve
                                                        uint32_t debug_leak_mod) {
   constexpr int NP = 2 * NQ, NPX = 4 * NQ;  // float2 pairs and pixels per lane
   __shared__ uint8_t cmap[32 * 256];
-  __shared__ uint32_t wlist[4][FRAG_WLIST];
+  __shared__ uint32_t wlist[FRAG_WAVES][FRAG_WLIST];
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(lv.colormap);
     uint4 *dst = reinterpret_cast<uint4 *>(cmap);
-    dst[threadIdx.x] = src[threadIdx.x];
-    dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+#pragma unroll
+    for (uint32_t k = threadIdx.x; k < 512u; k += 64u * FRAG_WAVES) dst[k] = src[k];
   }
   __syncthreads();
   // blockIdx -> (pose, chunk): all chunks of a pose on one XCD (b % 8), like the rasteriser
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) FRAG_OCCUPANCY void fragment_kernel(DeviceLeve
   const char *pvis_bytes = VIS16 ? reinterpret_cast<const char *>(pvis16) : reinterpret_cast<const char *>(pvis32);
   char *pfb_bytes = reinterpret_cast<char *>(pfb);
   for (uint32_t it = 0; it < chunk_iters; it++) {
-    const uint32_t wb = (chunk * chunk_iters + it) * 4u + wave;
+    const uint32_t wb = (chunk * chunk_iters + it) * FRAG_WAVES + wave;
     if (wb >= wblocks_per_pose) break;  // wave-uniform: past the end of the frame
     const uint32_t wby = wb / wblocks_per_row, wbx = wb - wby * wblocks_per_row;
     const uint32_t col = (wbx << bw_log2) + lane_col, row = (wby << (6u - bw_log2)) + lane_row;
@@ -556,7 +560,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
   const uint32_t bw = 1u << bwl, bh = 64u >> bwl;
   const uint32_t wbpr = (qpr / (uint32_t)nq + bw - 1u) / bw, wbpp = wbpr * (((uint32_t)H + bh - 1u) / bh);  // bw-unit x bh-row blocks
   const uint32_t frag_chunk = dbg.frag_chunk > 0 ? (uint32_t)dbg.frag_chunk : (uint32_t)FRAG_CHUNK;
-  const uint32_t fblocks = (wbpp + frag_chunk * 4u - 1u) / (frag_chunk * 4u);  // a workgroup = 4 waves x frag_chunk blocks
+  const uint32_t fblocks = (wbpp + frag_chunk * FRAG_WAVES - 1u) / (frag_chunk * FRAG_WAVES);  // a workgroup = FRAG_WAVES waves x frag_chunk blocks
   HIP_TRY(hipMemsetAsync(fix_count, 0, 2 * sizeof(uint32_t), st));
   const uint64_t fgrid = (uint64_t)((n + 7) / 8) * 8ull * fblocks;
   if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
@@ -567,7 +571,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
     frag = nq == 2 ? (vis16 ? fragment_kernel<2, 2, true> : fragment_kernel<2, 2, false>)
                    : (vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>);
 #endif
-  hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(256), 0, st, lv, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp,
+  hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(64 * FRAG_WAVES), 0, st, lv, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp,
                      qpr, div_m, div_sh, wbpr, wbpp, bwl, W, H, ndc_tab, fb, fix_count, fix_list, fix_cap, debug_leak_mod);
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, H, tiles_x, tiles_y,
                      tile_hdr, entries, entry_cap, overflow, fix_count, fix_list, fix_cap, vis, vis16 ? 1u : 0u, prim_out, fb,

@@ -231,7 +231,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 #ifndef RDOOM_RASTER_WAVES
-#define RDOOM_RASTER_WAVES 4
+#define RDOOM_RASTER_WAVES 1
 #endif
 constexpr uint32_t RASTER_WAVES = RDOOM_RASTER_WAVES;  // tiles (= waves) per workgroup
 
