@@ -230,13 +230,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return max(max(a, b), max(c, d));
 }
 
+#ifndef RDOOM_RASTER_OCC
+#define RDOOM_RASTER_OCC 4  // waves per SIMD the register allocation aims at (128 VGPRs)
+#endif
 #ifndef RDOOM_RASTER_WAVES
 #define RDOOM_RASTER_WAVES 1
 #endif
 constexpr uint32_t RASTER_WAVES = RDOOM_RASTER_WAVES;  // tiles (= waves) per workgroup
 
 template <bool STATS>
-__global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, 4) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+__global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                              const uint4 *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts, uint32_t cap,
                                                              uint32_t n_poses, int width, int height, int tiles_x,
