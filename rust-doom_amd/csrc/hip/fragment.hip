@@ -44,14 +44,19 @@ namespace {
 #ifdef RDOOM_FRAG_STATS  // census build (tools/variant.sh fstats fragment -DRDOOM_FRAG_STATS): where do the runs go?
 __device__ unsigned long long g_frag_stats[16];
 #endif
-constexpr int FRAG_CHUNK = 16;
+#ifndef RDOOM_FRAG_CHUNK
+#define RDOOM_FRAG_CHUNK 16
+#endif
+constexpr int FRAG_CHUNK = RDOOM_FRAG_CHUNK;
 #ifndef RDOOM_FRAG_WAVES
 #define RDOOM_FRAG_WAVES 4
 #endif
 constexpr uint32_t FRAG_WAVES = RDOOM_FRAG_WAVES;  // waves per workgroup (they share the LDS copy of COLORMAP)
 typedef uint32_t TexelWord __attribute__((aligned(2)));
-// six waves per SIMD: at most 80 VGPRs
-#define FRAG_OCCUPANCY __attribute__((amdgpu_waves_per_eu(6, 8)))
+#ifndef RDOOM_FRAG_OCC
+#define RDOOM_FRAG_OCC 6  // waves per SIMD the register allocation must allow: at most 80 VGPRs
+#endif
+#define FRAG_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RDOOM_FRAG_OCC, 8)))
 constexpr int FRAG_WLIST = 160;  // per-wave list of unfinished quads: at most 15 carried over + 64 x 2 new
 
 __device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const uint8_t *cmap, float px, float py,
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         loy = fmaxf(bv, size_y) * 0x1p-20f, hiy = size_y - loy;
         mod_ok = (p2x | (bu < 0x1p23f)) & (p2y | (bv < 0x1p23f));
       }
-      f32x2 ww[NP];
+      float w_first = 0.0f, w_last = 0.0f;  // 1/rw at the two ends of the run
       uint32_t texel[NPX], any_texel = 0;
       float rw_first = 0.0f, rw_last = 0.0f;
 #pragma unroll
@@ -286,9 +291,11 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         const f32x2 rw = pk_fma(splat(wa), px, splat(row_w));  // F1
         if (p == 0) rw_first = rw.x;
         if (p == NP - 1) rw_last = rw.y;
-        ww[p] = exact_rcp2(rw);
-        const f32x2 tu = pk_fma(splat(ua), px, splat(row_u)) * ww[p];
-        const f32x2 tv = pk_fma(splat(va), px, splat(row_v)) * ww[p];
+        const f32x2 w = exact_rcp2(rw);
+        if (p == 0) w_first = w.x;
+        if (p == NP - 1) w_last = w.y;
+        const f32x2 tu = pk_fma(splat(ua), px, splat(row_u)) * w;
+        const f32x2 tv = pk_fma(splat(va), px, splat(row_v)) * w;
         f32x2 fq = tu * splat(inv_s.x);  // F2: mod(t, size) = t - size * floor(t / size)
         fq = f32x2{floorf(fq.x), floorf(fq.y)};
         const f32x2 rx = pk_fma(splat(-size_x), fq, tu);
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         const f32x2 tt = (splat(1.0f) - lgt) * splat(32.0f);
         return f32x2{fminf(fmaxf(floorf(tt.x), 0.0f), 31.0f), fminf(fmaxf(floorf(tt.y), 0.0f), 31.0f)};
       };
-      const f32x2 rf_ends = rows_of(f32x2{ww[0].x, ww[NP - 1].y});
+      const f32x2 rf_ends = rows_of(f32x2{w_first, w_last});
       uint32_t ci[NPX];  // COLORMAP index = row * 256 + texel
       if (rf_ends.x == rf_ends.y) {
         const uint32_t r8 = (uint32_t)(int)rf_ends.x << 8;
@@ -330,7 +337,10 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
       } else {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-          const f32x2 rows = rows_of(ww[p]);
+          // (the ends disagree -- a few runs in a hundred: 1/rw of the pixels between them is evaluated again here
+          // rather than kept in eight registers through the whole body)
+          const f32x2 px = {px0 + (float)(2 * p), px0 + (float)(2 * p + 1)};
+          const f32x2 rows = rows_of(exact_rcp2(pk_fma(splat(wa), px, splat(row_w))));
           ci[2 * p] = ((uint32_t)(int)rows.x << 8) | (texel[2 * p] & 0xFFu);
           ci[2 * p + 1] = ((uint32_t)(int)rows.y << 8) | (texel[2 * p + 1] & 0xFFu);
         }

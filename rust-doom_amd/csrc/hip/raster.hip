@@ -352,6 +352,10 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
     }
   };
   if (single && count != 0u) gather(0u);
+#ifdef RDOOM_TIMING_EXPERIMENTS  // the list gather and record set-up run twice: the difference in kernel time is their cost
+  asm volatile("" ::: "memory");
+  if (single && count != 0u) gather(0u);
+#endif
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
     const int qx0 = tx0 + (q & 1) * 32, qy0 = ty0 + (q >> 1) * 32;  // this quadrant
