@@ -36,7 +36,8 @@ namespace {
 //   * mod by an integer tile size: floor(t * RN(1/size)) is certified by a remainder test (see F2)
 //   * COLORMAP row: every operation of F1/F4/F5 is monotone and rw is monotone along the run, so when the
 //     rows of the two end pixels agree every pixel between them has that row too
-// A run of sky is shaded from per-batch ndc tables.  A run that fails any precondition (mixed triangles,
+// A wave whose 512 pixels all show the same triangle takes the record by scalar loads (SGPR operands) -- the same
+// body, instantiated a second time.  A run of sky is shaded from per-batch ndc tables.  A run that fails any precondition (mixed triangles,
 // decor, rw outside the verified range, an uncertified mod, a transparent texel) is appended, quad by quad,
 // to a per-wave LDS list and shaded afterwards by the general per-pixel body, lane per pixel -- same
 // results, one code path for everything unusual.

@@ -203,8 +203,9 @@ __device__ __forceinline__ void raster_entry(const DeviceLevelView &lv, const Tr
 }
 
 // =================================================================================================
-// Kernel 2: tiled rasteriser, wave-autonomous.  One wavefront per (pose, 64x64 tile), four tiles per 256-thread
-// workgroup, no workgroup barriers.  The wave gathers the tile's list once and then rasterises the tile's four
+// Kernel 2: tiled rasteriser, wave-autonomous.  One wavefront per (pose, 64x64 tile), one tile per 64-thread workgroup
+// (a workgroup's registers and LDS come back when its last wave ends: with four tiles per workgroup three finished
+// waves waited for the slowest), no workgroup barriers.  The wave gathers the tile's list once and then rasterises the tile's four
 // 32x32 quadrants one after the other: in a quadrant each lane owns a 4x4 pixel block whose depth / winner live
 // in registers.  blockIdx -> (pose, tiles) keeps all tiles of a pose on one XCD (b % 8): its records stay in that
 // XCD's L2.
