@@ -55,8 +55,11 @@ __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *tmp) {
   return before + incl;
 }
 
+#ifndef RDOOM_BIN_OCC
+#define RDOOM_BIN_OCC 1  // waves per SIMD the register allocation must allow
+#endif
 template <int BIN_THREADS, int BIN_LOG2>  // threads per workgroup = triangles staged per round (one per thread)
-__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const TriRec *__restrict__ recs,
+__global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const TriRec *__restrict__ recs,
                                                           const uint4 *__restrict__ sorted,
                                                           const uint32_t *__restrict__ counts, uint32_t cap,
                                                           int tiles_x, int tiles_y, uint2 *__restrict__ tile_hdr,

@@ -72,6 +72,7 @@ def test_kat_level_and_odd_sizes(oracle_levels):
     lv = oracle_levels(1)
     run_case(lv, 64, 33, 6, rd.ALL_KINDS)      # partial tiles in both directions
     run_case(lv, 324, 201, 4, rd.ALL_KINDS)    # width a multiple of 4 but not of 8: one quad per lane
+    run_case(lv, 456, 120, 3, rd.ALL_KINDS)    # 7 x 64 + 8 pixels: the last 64x8 block of a row has one valid unit (no wave-uniform path there)
     run_case(lv, 1920, 1080, 2, rd.ALL_KINDS)  # BASELINE resolution
 
 
