@@ -45,6 +45,7 @@ def _load():
         _lib.oracle_render.restype = ctypes.c_int
         _lib.oracle_render_objects.restype = ctypes.c_int
         _lib.oracle_render_batch.restype = ctypes.c_int
+        _lib.oracle_render_varyings.restype = ctypes.c_int
     return _lib
 
 
@@ -97,6 +98,25 @@ class RasterOracle:
         if rc:
             raise MemoryError('oracle_render failed')
         return (fb, prim) if want_prim else fb
+
+    def render_varyings(self, modelview, projection, time, lights, width, height, kinds=ALL_KINDS):
+        """(fb, prim, var): the frame, the winning primitive ids and, per pixel, (v_tile_uv.x, v_tile_uv.y, v_dist) as the
+        oracle's binary32 arithmetic evaluates them for the winning fragment (census support, tests/gl_census.py)."""
+        lib = _load()
+        mv = np.ascontiguousarray(modelview, np.float32).reshape(16)
+        pr = np.ascontiguousarray(projection, np.float32).reshape(16)
+        li = np.ascontiguousarray(lights, np.uint8).reshape(256)
+        fb = np.zeros((height, width), np.uint8)
+        prim = np.zeros((height, width), np.uint32)
+        var = np.zeros((height, width, 3), np.float32)
+        rc = lib.oracle_render_varyings(ctypes.byref(self.level), mv.ctypes.data_as(ctypes.c_void_p),
+                                        pr.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(float(time)),
+                                        li.ctypes.data_as(ctypes.c_void_p), int(width), int(height), ctypes.c_uint32(kinds),
+                                        fb.ctypes.data_as(ctypes.c_void_p), prim.ctypes.data_as(ctypes.c_void_p),
+                                        var.ctypes.data_as(ctypes.c_void_p))
+        if rc:
+            raise MemoryError('oracle_render_varyings failed')
+        return fb, prim, var
 
     def render_batch(self, poses, lights, width, height, kinds=ALL_KINDS, threads=1):
         """poses: (n,33) float32 [modelview16, projection16, time]; lights: (n,256) u8."""

@@ -18,8 +18,8 @@
  * independently against that text; this file is the checker.  It is never linked into the product.
  *
  * PARITY PIN STATUS: pinned against GL readbacks of the reference's own six shaders, executed headless by SwiftShader
- * (tests/gl_readback.py, fixtures tests/golden/gl_readback/, tests/test_gl_readback.py): 98.5 % of 4 761 600 pixels
- * identical, every other pixel explained by a discontinuity GL leaves to the implementation (tests/gl_census.py);
+ * (tests/gl_readback.py, fixtures tests/golden/gl_readback/, tests/test_gl_readback.py): 99.5 % of 93.7 M pixels in 142
+ * frames identical, every other pixel explained by a discontinuity GL leaves to the implementation (tests/gl_census.py);
  * plus analytic KATs (tests/test_kat_analytic.py) and golden digests (tests/golden/).
  */
 #include <math.h>
@@ -191,12 +191,13 @@ static int setup_tri(const float clip[3][4], const float u[3], const float v[3],
 static float plane(const float *p, float px, float py) { return fmaf(p[0], px, fmaf(p[1], py, p[2])); }
 
 /* static.frag:19-20 texel fetch.  Returns the raw texel (u16; flats are promoted, never transparent). */
-static uint32_t fetch_texel(const OracleLevel *L, const Setup *s, float px, float py, float *dist) {
+static uint32_t fetch_texel(const OracleLevel *L, const Setup *s, float px, float py, float *dist, float *tuv) {
   float rw = plane(s->wp, px, py);
   float w = 1.0f / rw;
   float tu = plane(s->up, px, py) * w;
   float tv = plane(s->vp, px, py) * w;
   *dist = w;
+  if (tuv) tuv[0] = tu, tuv[1] = tv;
   float uvx = glsl_mod(tu, s->size_x) + s->atlas_u;
   float uvy = glsl_mod(tv, s->size_y) + s->atlas_v;
   int ix = (int)floorf(uvx), iy = (int)floorf(uvy);
@@ -291,7 +292,7 @@ static uint8_t shade_sky(const OracleLevel *L, float px, float py, int width, in
 static int render_with_scratch(const OracleLevel *L, const float *modelview, const float *projection, float time,
                                const uint8_t *lights, int width, int height, uint32_t kinds_mask, uint8_t *out_fb,
                                uint32_t *out_prim, uint32_t *depth, uint32_t *prim, const float *object_modelviews,
-                               uint32_t n_objects) {
+                               uint32_t n_objects, float *out_var) {
   size_t npx = (size_t)width * (size_t)height;
   for (size_t i = 0; i < npx; i++) {
     depth[i] = 0xFFFFFFFFu;
@@ -367,18 +368,22 @@ static int render_with_scratch(const OracleLevel *L, const float *modelview, con
           size_t o = (size_t)iy * (size_t)width + (size_t)ix;
           if (!(d24 < depth[o])) continue; /* LESS: the earlier primitive keeps ties */
           uint8_t colour;
+          float var[3] = {0.0f, 0.0f, 0.0f};
           if (dr->kind == KIND_SKY) {
             colour = shade_sky(L, px, py, width, height, vr);
           } else {
             float dist;
-            uint32_t texel = fetch_texel(L, &s, px, py, &dist);
+            float tuv[2];
+            uint32_t texel = fetch_texel(L, &s, px, py, &dist, tuv);
             if (dr->kind != KIND_FLAT && (texel & 0x8000u)) continue; /* static.frag:21 / sprite.frag:20 discard */
             colour = dr->kind == KIND_DECOR ? shade_decor(L, texel & 0xFFu, s.light, dist)
                                             : shade(L, texel & 0xFFu, s.light, dist);
+            var[0] = tuv[0], var[1] = tuv[1], var[2] = dist;
           }
           depth[o] = d24;
           prim[o] = prim_id;
           out_fb[o] = colour;
+          if (out_var && dr->kind != KIND_SKY) out_var[3 * o] = var[0], out_var[3 * o + 1] = var[1], out_var[3 * o + 2] = var[2];
         }
       }
     }
@@ -396,7 +401,7 @@ int oracle_render(const OracleLevel *L, const float *modelview, const float *pro
   int rc = -1;
   if (depth && prim)
     rc = render_with_scratch(L, modelview, projection, time, lights, width, height, kinds_mask, out_fb, out_prim, depth,
-                             prim, 0, 0);
+                             prim, 0, 0, 0);
   free(depth);
   free(prim);
   return rc;
@@ -411,7 +416,7 @@ int oracle_render_objects(const OracleLevel *L, const float *modelview, const fl
   int rc = -1;
   if (depth && prim)
     rc = render_with_scratch(L, modelview, projection, time, lights, width, height, kinds_mask, out_fb, out_prim, depth,
-                             prim, object_modelviews, n_objects);
+                             prim, object_modelviews, n_objects, 0);
   free(depth);
   free(prim);
   return rc;
@@ -428,7 +433,26 @@ int oracle_render_batch(const OracleLevel *L, const float *poses, const uint8_t 
   for (int i = 0; i < n && !rc; i++) {
     const float *p = poses + (size_t)i * 33;
     rc = render_with_scratch(L, p, p + 16, p[32], lights + (size_t)i * 256, width, height, kinds_mask,
-                             out_fb + (size_t)i * npx, 0, depth, prim, 0, 0);
+                             out_fb + (size_t)i * npx, 0, depth, prim, 0, 0, 0);
+  }
+  free(depth);
+  free(prim);
+  return rc;
+}
+
+/* Census support (tests/gl_census.py): the frame plus, per pixel, the varyings the winning fragment was shaded from --
+ * v_tile_uv.x, v_tile_uv.y, v_dist as THIS arithmetic evaluates them (sky and background pixels: zeros). */
+int oracle_render_varyings(const OracleLevel *L, const float *modelview, const float *projection, float time,
+                           const uint8_t *lights, int width, int height, uint32_t kinds_mask, uint8_t *out_fb,
+                           uint32_t *out_prim, float *out_var) {
+  size_t npx = (size_t)width * (size_t)height;
+  uint32_t *depth = (uint32_t *)malloc(npx * sizeof(uint32_t));
+  uint32_t *prim = (uint32_t *)malloc(npx * sizeof(uint32_t));
+  int rc = -1;
+  if (depth && prim) {
+    memset(out_var, 0, npx * 3 * sizeof(float));
+    rc = render_with_scratch(L, modelview, projection, time, lights, width, height, kinds_mask, out_fb, out_prim, depth,
+                             prim, 0, 0, out_var);
   }
   free(depth);
   free(prim);

@@ -11,7 +11,8 @@ positions displaced by up to JITTER pixels (the reach of a 1/16-pixel vertex sna
   * winners differ and the centre is within JITTER of an edge of either winner, or either winner is thinner than
     JITTER there (nearly collinear fan triangles: facing and coverage are decided by rounding) -> `edge`
   * winners differ, an alpha-tested winner's opacity flips within JITTER                 -> `alpha texel boundary`
-  * winners differ, both cover robustly, depths within DEPTH_TIE                         -> `depth tie`
+  * winners differ, both cover robustly, depths within DEPTH_TIE at the centre or at
+    samples displaced by up to JITTER (grazing surfaces: many depth steps per pixel)       -> `depth tie`
   * same winner; the reference's fragment arithmetic applied to the varyings GL ITSELF interpolated at the pixel
     (auxiliary pass, within VARYING_TOL of the float64 value), or to a displaced sample, reproduces the GL colour
     through another texel                                                                -> `texel boundary`
@@ -29,7 +30,12 @@ JITTER = 0.0625          # pixels = 2^-GL_SUBPIXEL_BITS: what GL guarantees abou
 DEPTH_TIE = 3.0 / 16777215.0
 VARYING_TOL_ABS = 1.0 / 16.0      # texels: how far GL's own interpolated v_tile_uv may sit from the float64 value ...
 VARYING_TOL_REL = 1.0 / 128.0     # ... plus this fraction of its magnitude (and of v_dist): SwiftShader's measured envelope
-ROUNDING_MARGIN = 2.0 ** -11      # binary32 plane evaluation vs float64 at the pixel centre, relative to the coordinate (far slivers: measured 2.1e-4)
+ROUNDING_MARGIN = 2.0 ** -11      # binary32 v_dist vs float64 at the pixel centre, relative (far slivers: measured 2.1e-4)
+# binary32 v_tile_uv vs float64 at the pixel centre: ROUNDING_K unit roundoffs of the planes' condition sums
+# (|a x| + |b y| + |c|) / rw for u/w, plus |tu| times the same for 1/w.  Measured on 100 000 pixels of five 1920x1080
+# frames through oracle_render_varyings: median 0.3, 99.9 % below 8.7, maximum 36 (a wall seen edge-on: 128 texels over
+# 4 pixels, condition sum 1.4e5, 0.025 texels off).  Well-conditioned pixels get a far smaller margin than before.
+ROUNDING_K = 64.0
 CLASSES = ('edge', 'alpha texel boundary', 'depth tie', 'texel boundary', 'colormap-row boundary', 'other')
 
 
@@ -122,10 +128,18 @@ class F64Frame:
         self._cache[pid] = s
         return s
 
-    def fragment(self, pid, tu, tv, dist):
-        """static.frag:19-26 / sprite.frag:19-26 in float64 on given varyings (v_tile_uv, v_dist)."""
+    def fragment(self, pid, tu, tv, dist, binary32=False):
+        """static.frag:19-26 / sprite.frag:19-26 in float64 on given varyings (v_tile_uv, v_dist).  binary32: the texel
+        coordinate `mod(v_tile_uv, u_tile_size) + u_atlas_uv` rounded the way the shader's highp floats round it -- just
+        below a tile's far edge the sum rounds UP onto the first texel of the neighbouring atlas entry."""
         s = self._tri(pid)
-        uvx, uvy = _mod(tu, s['size'][0]) + s['atlas_uv'][0], _mod(tv, s['size'][1]) + s['atlas_uv'][1]
+        if binary32:
+            f = np.float32
+            with np.errstate(all='ignore'):
+                m = [f(t) - f(z) * np.floor(f(t) / f(z)) for t, z in ((tu, s['size'][0]), (tv, s['size'][1]))]
+                uvx, uvy = float(f(m[0]) + f(s['atlas_uv'][0])), float(f(m[1]) + f(s['atlas_uv'][1]))
+        else:
+            uvx, uvy = _mod(tu, s['size'][0]) + s['atlas_uv'][0], _mod(tv, s['size'][1]) + s['atlas_uv'][1]
         a = self.atlas[s['kind']]
         ix, iy = int(math.floor(uvx)) & (a.shape[1] - 1), int(math.floor(uvy)) & (a.shape[0] - 1)
         texel = int(a[iy, ix])
@@ -187,6 +201,8 @@ class F64Frame:
             return out
         wq = 1.0 / rw
         out.update(self.fragment(pid, ev(s['up']) * wq, ev(s['vp']) * wq, wq))
+        ab = lambda p: abs(p[0] * x) + abs(p[1] * y) + abs(p[2])  # noqa: E731
+        out['uv_cond'] = max(ab(s['up']) + abs(out['tuv'][0]) * ab(s['wp']), ab(s['vp']) + abs(out['tuv'][1]) * ab(s['wp'])) * wq
         return out
 
 
@@ -221,13 +237,37 @@ def _edges_within_jitter(f64, pid, x, y):
     return n
 
 
+def _tile_edge_opacities(f64, pid, around):
+    """Opacity of the texels a fragment of `pid` can fetch where v_tile_uv crosses a multiple of the tile size inside the
+    jitter square: just below the multiple, the shader's binary32 sum `mod(v_tile_uv, size) + atlas_uv` rounds UP to
+    atlas_uv + size, the first texel of the neighbouring atlas entry (the zone is a fraction of a binary32 step wide -- no
+    sample grid meets it, so the neighbouring texel is looked up directly)."""
+    pts = [s for s in around if s is not None and 'tuv' in s and s['kind'] != KIND_SKY]
+    out = set()
+    if not pts:
+        return out
+    tri = f64._tri(pid)
+    if tri['kind'] == KIND_FLAT:
+        return out   # flats are never alpha-tested
+    size, atlas_uv, a = tri['size'], tri['atlas_uv'], f64.atlas[tri['kind']]
+    for axis in (0, 1):
+        lo, hi = min(s['tuv'][axis] for s in pts), max(s['tuv'][axis] for s in pts)
+        if math.ceil(lo / size[axis]) * size[axis] <= hi:   # a tile boundary inside the square
+            for s in pts:
+                uv = [_mod(s['tuv'][0], size[0]) + atlas_uv[0], _mod(s['tuv'][1], size[1]) + atlas_uv[1]]
+                uv[axis] = atlas_uv[axis] + size[axis]
+                texel = int(a[int(math.floor(uv[1])) & (a.shape[0] - 1), int(math.floor(uv[0])) & (a.shape[1] - 1)])
+                out.add(not texel & 0x8000)
+    return out
+
+
 def _which_boundary(centre, other):
     if other['texel'] != centre['texel']:
         return 'texel boundary'
     if other['row'] != centre['row']:
         return 'colormap-row boundary'
     # float64 agrees with GL at the centre: the binary32 oracle rounded across a boundary float64 resolves the other way
-    if centre['texel_margin'] <= ROUNDING_MARGIN * max(1.0, abs(centre['tuv'][0]), abs(centre['tuv'][1])):
+    if centre['texel_margin'] <= ROUNDING_K * 2.0 ** -23 * centre.get('uv_cond', 0.0):
         return 'texel boundary'
     if centre['row_margin'] <= ROUNDING_MARGIN * 32.0:
         return 'colormap-row boundary'
@@ -253,10 +293,22 @@ def classify_pixel(f64, ix, iy, oracle_prim, gl_prim, gl_rgb, gl_var, rgb_of_ind
             if p in none:
                 continue
             around = [f64.sample(int(p), x + dx, y + dy) for dx, dy in _OFFSETS]
-            if len({bool(s['opaque']) for s in around if s is not None}) > 1:
+            opacities = {bool(s['opaque']) for s in around if s is not None}
+            # ... and with the texel coordinate rounded as the shader's binary32 sum rounds it: within 2^-16 of a tile's far
+            # edge `mod(v_tile_uv, size) + atlas_uv` lands on the neighbouring atlas entry, whose texel may be transparent
+            opacities |= _tile_edge_opacities(f64, int(p), around)
+            if len(opacities) > 1:
                 return 'alpha texel boundary'
-        if len(samples) == 2 and abs(samples[0]['z'] - samples[1]['z']) <= DEPTH_TIE:
-            return 'depth tie'
+        if len(samples) == 2:
+            # depths closer than the depth buffer resolves, at the centre or anywhere a 1/16-pixel vertex snap can move
+            # the sample to: on surfaces seen at a grazing angle the depth changes by many buffer steps per pixel, so the
+            # snap alone shifts it by several (1920x1080 frames: up to 19 steps measured between near-coplanar walls)
+            spans = []
+            for p in (oracle_prim, gl_prim):
+                zs = [s['z'] for s in (f64.sample(int(p), x + dx, y + dy) for dx, dy in _OFFSETS) if s is not None]
+                spans.append((min(zs), max(zs)))
+            if spans[0][0] - DEPTH_TIE <= spans[1][1] and spans[1][0] - DEPTH_TIE <= spans[0][1]:
+                return 'depth tie'
         return 'other'
     if oracle_prim in none:
         return 'other'
@@ -271,6 +323,10 @@ def classify_pixel(f64, ix, iy, oracle_prim, gl_prim, gl_rgb, gl_var, rgb_of_ind
             g = f64.fragment_sky(gv[0], gv[1]) if gv[2] == -1.0 else None
         else:
             g = f64.fragment(pid, gv[0], gv[1], gv[2]) if gv[2] > 0.0 else None
+        if g is not None and centre['kind'] != KIND_SKY and tuple(rgb_of_index[g['colour']]) != want:
+            g32 = f64.fragment(pid, gv[0], gv[1], gv[2], binary32=True)
+            if tuple(rgb_of_index[g32['colour']]) == want:
+                g = g32
         if g is not None and tuple(rgb_of_index[g['colour']]) == want:
             duv = max(abs(g['tuv'][0] - centre['tuv'][0]), abs(g['tuv'][1] - centre['tuv'][1]))
             scale = max(abs(centre['tuv'][0]), abs(centre['tuv'][1]))

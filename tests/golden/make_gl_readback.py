@@ -7,7 +7,7 @@
   * three frames with moving objects (per-object u_modelview, engine/src/renderer.rs:120-132),
   * twelve targeted views of E1M1: under open sky looking up, close to decorations, along scrolling / animated
     textures at non-zero times,
-  * pose 0 of the benchmark sweep at 1920x1080 (BASELINE config 3's frame size),
+  * poses 0, 341, 682 and 1000 of the benchmark sweep at 1920x1080 (BASELINE config 3's frame size),
 
 each with the auxiliary winner-id pass, and the mismatch census of the ORACLE's frame against them
 (tests/gl_census.py).  The readbacks are committed so that the GPU box -- which has neither the reference checkout nor
@@ -98,22 +98,53 @@ def targeted_frames(levels):
     return out
 
 
-def bench_pose(width, height):
-    """pose 0 of the benchmark sweep of E1M1 (rust-doom_amd/sharding.py: pose_sweep)"""
+def bench_pose(width, height, index=0):
+    """pose `index` of the benchmark sweep of E1M1 (rust-doom_amd/sharding.py: pose_sweep)"""
     import importlib
     import rust_doom_amd as rd
     sharding = importlib.import_module('rust-doom_amd.sharding')
     built = rd.Wad(ensure_wad(), META_PATH).build_level(0)
-    p = sharding.pose_sweep(rd, built, 1, width, height)[0]
+    p = sharding.pose_sweep(rd, built, 1, width, height, first=index)[0]
     out = np.zeros(33, np.float32)
     out[:16], out[16:32], out[32] = p['modelview'], p['projection'], p['time']
     return out
+
+
+def sweep_pose(index, width, height, i):
+    """pose i of level `index`'s benchmark sweep (rust-doom_amd/sharding.py: pose_sweep)"""
+    import importlib
+    import rust_doom_amd as rd
+    sharding = importlib.import_module('rust-doom_amd.sharding')
+    built = rd.Wad(ensure_wad(), META_PATH).build_level(index)
+    p = sharding.pose_sweep(rd, built, 1, width, height, first=i)[0]
+    out = np.zeros(33, np.float32)
+    out[:16], out[16:32], out[32] = p['modelview'], p['projection'], p['time']
+    return out
+
+
+def extended_frames():
+    out = [('L0_bench%d_1080p' % i, 0, 1920, 1080, sweep_pose(0, 1920, 1080, i)) for i in range(16, 1024, 32)]
+    for index in range(1, 9):
+        out += [('L%d_sweep%d_640' % (index, i), index, 640, 400, sweep_pose(index, 640, 400, i)) for i in range(0, 1024, 128)]
+    return out
+
+
+def extended_census(lv, glref, oracle, pose, w, h):
+    mv, pr, t = pose[:16], pose[16:32], float(pose[32])
+    lights = lv.lights.fill_buffer_at(t)
+    rgb = glref.render(mv, pr, t, lights, w, h)
+    gid = glref.render(mv, pr, t, lights, w, h, mode='ids')
+    var = glref.render(mv, pr, t, lights, w, h, mode='varyings')
+    fb, prim = oracle.render(mv, pr, t, lights, w, h, want_prim=True)
+    return gl_census.census(lv, mv, pr, t, lights, w, h, fb, prim, rgb, gid, var)
 
 
 def main():
     wad = ensure_wad()
     frames = frame_list()
     frames.append(('L0_bench0_1080p', 0, 1920, 1080, bench_pose(1920, 1080), None))
+    for i in (341, 682, 1000):  # three more poses of the sweep at BASELINE config 3's frame size
+        frames.append(('L0_bench%d_1080p' % i, 0, 1920, 1080, bench_pose(1920, 1080, i), None))
     levels, gls, oracles = {}, {}, {}
     levels[0] = wad_oracle.build_level(wad, META_PATH, 0)
     frames += targeted_frames(lambda i: levels[i])
@@ -143,6 +174,21 @@ def main():
     tot = {k: sum(f[k] for f in census['frames'].values()) for k in ('pixels', 'mismatch', 'winner_mismatch') + gl_census.CLASSES}
     census['total'] = tot
     print('total', tot, 'mismatch fraction %.4f' % (tot['mismatch'] / tot['pixels']))
+    # Extended census: counts only (no readbacks are stored for these frames), a wider net for systematic differences --
+    # every 32nd pose of the benchmark sweep at 1920x1080 and eight poses of each other level's sweep at 640x400.
+    census['extended'] = {}
+    for key, index, w, h, pose in extended_frames():
+        if index not in levels:
+            levels[index] = wad_oracle.build_level(wad, META_PATH, index)
+        if index not in gls:
+            gls[index] = gl_readback.GLReference(levels[index])
+            oracles[index] = raster.RasterOracle(levels[index])
+        census['extended'][key] = c = extended_census(levels[index], gls[index], oracles[index], pose, w, h)
+        c.update(level=index, width=w, height=h)
+        print(key, {k: v for k, v in c.items() if k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES})
+    etot = {k: sum(f[k] for f in census['extended'].values()) for k in ('pixels', 'mismatch', 'winner_mismatch') + gl_census.CLASSES}
+    census['extended_total'] = etot
+    print('extended total', etot, 'mismatch fraction %.4f' % (etot['mismatch'] / etot['pixels']))
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, 'frames.npz'), **arrays)
     with open(os.path.join(OUT, 'census.json'), 'w') as f:

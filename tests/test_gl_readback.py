@@ -4,9 +4,10 @@ and the HIP renderer.
 
 Committed under tests/golden/gl_readback/ (generator: tests/golden/make_gl_readback.py): the GL readbacks (RGB), the
 primitive SwiftShader's rasteriser chose per pixel, and the mismatch census of the oracle's frames against them --
-43 frames: the 27 golden poses at 320x200 (level 0 pose 0 = BASELINE config 2: E1M1, spawn pose, 320x200), three frames
-with moving objects, twelve targeted views (sky, decorations, scrolling / animated textures), pose 0 of the benchmark
-sweep at 1920x1080.
+46 frames: the 27 golden poses at 320x200 (level 0 pose 0 = BASELINE config 2: E1M1, spawn pose, 320x200), three frames
+with moving objects, twelve targeted views (sky, decorations, scrolling / animated textures), poses 0, 341, 682 and 1000 of
+the benchmark sweep at 1920x1080.  An EXTENDED census (counts only, no stored readbacks: 32 more poses of that sweep at
+1920x1080 and eight poses of every other level at 640x400, 82.7 M pixels) widens the net for systematic differences.
 
 What is asserted:
   * every mismatching pixel is explained by a discontinuity GL leaves to the implementation (tests/gl_census.py):
@@ -16,8 +17,9 @@ What is asserted:
     regenerated from the reference's shader files and must equal the committed ones;
   * (gpu) the HIP renderer's frames have exactly the oracle's mismatch sets against the GL readbacks.
 
-Bounds (measured: 1.50 % of 4 761 600 pixels differ; 96.4 % of those are texel-boundary picks caused by SwiftShader's
-~13-bit perspective interpolation, 2.0 % lie on primitive edges; winners differ on 0.076 %):"""
+Bounds (measured: 0.84 % of the 10 982 400 stored pixels and 0.44 % of the 82 739 200 extended ones differ; 95 % of those
+are texel-boundary picks caused by SwiftShader's ~13-bit perspective interpolation, 2.4 % lie on primitive edges; winners
+differ on 0.03 - 0.05 %):"""
 import importlib.util
 import json
 import os
@@ -62,6 +64,19 @@ def mismatch_counts(lv, key, fb, prim):
             int(((prim & 0xFFFFFF) != (FRAMES[key + '_prim'] & 0xFFFFFF)).sum()))
 
 
+def test_extended_census_is_clean_and_bounded():
+    tot = CENSUS['extended_total']
+    assert tot['other'] == 0 and all(f['other'] == 0 for f in CENSUS['extended'].values())
+    assert tot['pixels'] >= 80_000_000 and len(CENSUS['extended']) >= 96
+    assert tot['mismatch'] <= MAX_MISMATCH_TOTAL * tot['pixels'], tot
+    assert tot['winner_mismatch'] <= MAX_WINNER_MISMATCH_TOTAL * tot['pixels'], tot
+    for k, f in CENSUS['extended'].items():
+        assert f['mismatch'] <= MAX_MISMATCH_FRAME * f['pixels'], (k, f)
+        assert sum(f[c] for c in gl_census.CLASSES) == f['mismatch'], k
+    assert sum(1 for f in CENSUS['extended'].values() if f['width'] == 1920) >= 32
+    assert {f['level'] for f in CENSUS['extended'].values()} == set(range(9))
+
+
 def test_census_is_clean_and_bounded():
     tot = CENSUS['total']
     assert tot['other'] == 0
@@ -97,6 +112,19 @@ def test_swiftshader_runs_the_reference_shaders(oracle_levels, key):
     assert np.array_equal(rgb, FRAMES[key + '_rgb']) and np.array_equal(gid, FRAMES[key + '_prim'])
     fb, prim = raster.RasterOracle(lv).render(mv, pr, t, lights, w, h, want_prim=True, object_modelviews=om)
     got = gl_census.census(lv, mv, pr, t, lights, w, h, fb, prim, rgb, gid, var, object_modelviews=om)
+    assert got['other'] == 0
+    for k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES:
+        assert got[k] == c[k], (k, got[k], c[k])
+
+
+@pytest.mark.skipif(not gl_readback.available(), reason='needs SwiftShader and the reference checkout (/root/reference)')
+@pytest.mark.parametrize('key', ['L0_bench624_1080p', 'L5_sweep128_640', 'L8_sweep896_640'])
+def test_swiftshader_extended_census(oracle_levels, key):
+    """regenerates the counts of extended frames (nothing stored but the counts) from the reference's shader files"""
+    c = CENSUS['extended'][key]
+    lv = oracle_levels(c['level'])
+    pose = dict((k, p) for k, _i, _w, _h, p in gen.extended_frames() if k == key)[key]
+    got = gen.extended_census(lv, gl_readback.GLReference(lv), raster.RasterOracle(lv), pose, c['width'], c['height'])
     assert got['other'] == 0
     for k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES:
         assert got[k] == c[k], (k, got[k], c[k])
