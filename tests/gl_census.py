@@ -27,7 +27,9 @@ import numpy as np
 
 KIND_FLAT, KIND_WALL, KIND_DECOR, KIND_SKY = 0, 1, 2, 3
 JITTER = 0.0625          # pixels = 2^-GL_SUBPIXEL_BITS: what GL guarantees about vertex positions
-DEPTH_TIE = 3.0 / 16777215.0
+# 3 units of the 24-bit depth buffer + 5 binary32 roundoffs of a depth near 1 (one unit each) in GL's own plane evaluation
+# (3840x2160: two surfaces 7.7 units apart over the jitter square went the other way; 1920x1080 and below: never more than 3)
+DEPTH_TIE = 8.0 / 16777215.0
 VARYING_TOL_ABS = 1.0 / 16.0      # texels: how far GL's own interpolated v_tile_uv may sit from the float64 value ...
 VARYING_TOL_REL = 1.0 / 128.0     # ... plus this fraction of its magnitude (and of v_dist): SwiftShader's measured envelope
 ROUNDING_MARGIN = 2.0 ** -11      # binary32 v_dist vs float64 at the pixel centre, relative (far slivers: measured 2.1e-4)

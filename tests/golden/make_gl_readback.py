@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import gl_census  # noqa: E402
 import gl_readback  # noqa: E402
 from oracle import raster, wad_oracle  # noqa: E402
-from util import GOLDEN, META_PATH, ensure_wad  # noqa: E402
+from util import GOLDEN, META_PATH, ensure_big_wad, ensure_wad  # noqa: E402
 
 OUT = os.path.join(GOLDEN, 'gl_readback')
 
@@ -110,33 +110,56 @@ def bench_pose(width, height, index=0):
     return out
 
 
-def sweep_pose(index, width, height, i):
-    """pose i of level `index`'s benchmark sweep (rust-doom_amd/sharding.py: pose_sweep)"""
+_BUILT = {}
+
+
+def sweep_pose(index, width, height, i, time=0.0, big=False):
+    """pose i of the benchmark sweep (rust-doom_amd/sharding.py: pose_sweep) of level `index` of the synthetic IWAD, or of
+    the 10 x E1M1 level (big: the MAP29 stand-in), at `time`"""
     import importlib
     import rust_doom_amd as rd
     sharding = importlib.import_module('rust-doom_amd.sharding')
-    built = rd.Wad(ensure_wad(), META_PATH).build_level(index)
-    p = sharding.pose_sweep(rd, built, 1, width, height, first=i)[0]
+    if (index, big) not in _BUILT:
+        _BUILT[(index, big)] = rd.Wad(ensure_big_wad() if big else ensure_wad(), META_PATH).build_level(index)
+    p = sharding.pose_sweep(rd, _BUILT[(index, big)], 1, width, height, first=i, time=time)[0]
     out = np.zeros(33, np.float32)
     out[:16], out[16:32], out[32] = p['modelview'], p['projection'], p['time']
     return out
 
 
 def extended_frames():
-    out = [('L0_bench%d_1080p' % i, 0, 1920, 1080, sweep_pose(0, 1920, 1080, i)) for i in range(16, 1024, 32)]
+    """(key, level key, width, height, pose[33], object seed or None); level key = index, or 'big' for the 10 x E1M1 level"""
+    out = [('L0_bench%d_1080p' % i, 0, 1920, 1080, sweep_pose(0, 1920, 1080, i), None) for i in range(16, 1024, 32)]
     for index in range(1, 9):
-        out += [('L%d_sweep%d_640' % (index, i), index, 640, 400, sweep_pose(index, 640, 400, i)) for i in range(0, 1024, 128)]
+        out += [('L%d_sweep%d_640' % (index, i), index, 640, 400, sweep_pose(index, 640, 400, i), None) for i in range(0, 1024, 128)]
+    # time-varying state (animated flats, scrolling walls, the light table of that time) with every door / lift displaced
+    for index in range(9):
+        for k, i in enumerate((40, 424, 808)):
+            t = (1.7, 9.1, 27.5)[k] + index
+            out.append(('L%d_sweep%d_t%.1f_objects_640' % (index, i, t), index, 640, 400, sweep_pose(index, 640, 400, i, time=t), 1000 + 16 * index + k))
+    # BASELINE config 5's frame size, time-varying (the synthetic E1M3 and E1M1)
+    for index, i, t in ((2, 5, 2.3), (2, 517, 6.9), (0, 261, 12.4), (0, 773, 0.0)):
+        out.append(('L%d_sweep%d_t%.1f_2160p' % (index, i, t), index, 3840, 2160, sweep_pose(index, 3840, 2160, i, time=t), None))
+    # the 10 x E1M1 level (38 k triangles: the MAP29 stand-in)
+    out += [('big_sweep%d_1080p' % i, 'big', 1920, 1080, sweep_pose(0, 1920, 1080, i, big=True), None) for i in (3, 259, 515, 771)]
     return out
 
 
-def extended_census(lv, glref, oracle, pose, w, h):
+def extended_census(lv, glref, oracle, pose, w, h, obj_seed=None):
     mv, pr, t = pose[:16], pose[16:32], float(pose[32])
     lights = lv.lights.fill_buffer_at(t)
-    rgb = glref.render(mv, pr, t, lights, w, h)
-    gid = glref.render(mv, pr, t, lights, w, h, mode='ids')
-    var = glref.render(mv, pr, t, lights, w, h, mode='varyings')
-    fb, prim = oracle.render(mv, pr, t, lights, w, h, want_prim=True)
-    return gl_census.census(lv, mv, pr, t, lights, w, h, fb, prim, rgb, gid, var)
+    om = None if obj_seed is None else moving_object_views(lv, mv, obj_seed)
+    rgb = glref.render(mv, pr, t, lights, w, h, object_modelviews=om)
+    gid = glref.render(mv, pr, t, lights, w, h, mode='ids', object_modelviews=om)
+    var = glref.render(mv, pr, t, lights, w, h, mode='varyings', object_modelviews=om)
+    fb, prim = oracle.render(mv, pr, t, lights, w, h, want_prim=True, object_modelviews=om)
+    return gl_census.census(lv, mv, pr, t, lights, w, h, fb, prim, rgb, gid, var, object_modelviews=om)
+
+
+def extended_level(levels, key):
+    if key not in levels:
+        levels[key] = wad_oracle.build_level(ensure_big_wad() if key == 'big' else ensure_wad(), META_PATH, 0 if key == 'big' else key)
+    return levels[key]
 
 
 def main():
@@ -175,16 +198,16 @@ def main():
     census['total'] = tot
     print('total', tot, 'mismatch fraction %.4f' % (tot['mismatch'] / tot['pixels']))
     # Extended census: counts only (no readbacks are stored for these frames), a wider net for systematic differences --
-    # every 32nd pose of the benchmark sweep at 1920x1080 and eight poses of each other level's sweep at 640x400.
+    # every 32nd pose of the benchmark sweep at 1920x1080, eight poses of each other level's sweep at 640x400, time-varying
+    # frames with displaced doors / lifts on every level, 3840x2160 frames, the 10 x E1M1 level.
     census['extended'] = {}
-    for key, index, w, h, pose in extended_frames():
-        if index not in levels:
-            levels[index] = wad_oracle.build_level(wad, META_PATH, index)
+    for key, index, w, h, pose, obj_seed in extended_frames():
+        lv = extended_level(levels, index)
         if index not in gls:
-            gls[index] = gl_readback.GLReference(levels[index])
-            oracles[index] = raster.RasterOracle(levels[index])
-        census['extended'][key] = c = extended_census(levels[index], gls[index], oracles[index], pose, w, h)
-        c.update(level=index, width=w, height=h)
+            gls[index] = gl_readback.GLReference(lv)
+            oracles[index] = raster.RasterOracle(lv)
+        census['extended'][key] = c = extended_census(lv, gls[index], oracles[index], pose, w, h, obj_seed)
+        c.update(level=index, width=w, height=h, time=float(pose[32]), objects_seed=obj_seed)
         print(key, {k: v for k, v in c.items() if k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES})
     etot = {k: sum(f[k] for f in census['extended'].values()) for k in ('pixels', 'mismatch', 'winner_mismatch') + gl_census.CLASSES}
     census['extended_total'] = etot
