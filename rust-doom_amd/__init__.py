@@ -260,6 +260,14 @@ def make_visitor(obj):
     return vt, keep
 
 
+def _close_quietly(obj):
+    """__del__ of the handle classes: at interpreter shutdown the module's globals may already be gone"""
+    try:
+        obj.close()
+    except Exception:
+        pass
+
+
 class Wad:
     """wad::Archive + TextureDirectory behind rdoom_wad_open (wad/src/archive.rs:36-60, tex.rs:53-107)."""
 
@@ -272,7 +280,8 @@ class Wad:
             lib().rdoom_wad_close(self._h)
             self._h = ctypes.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        _close_quietly(self)
 
     def num_levels(self):
         n = ctypes.c_uint32()
@@ -316,7 +325,8 @@ class BuiltLevel:
             lib().rdoom_built_destroy(self._h)
             self._h = ctypes.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        _close_quietly(self)
 
     def _view(self, ptr, count, dtype):
         if not ptr or count == 0:
@@ -389,7 +399,8 @@ class DeviceLevel:
             lib().rdoom_level_destroy(self._h)
             self._h = ctypes.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        _close_quietly(self)
 
 
 class Batch:
@@ -406,7 +417,8 @@ class Batch:
             lib().rdoom_batch_destroy(self._h)
             self._h = ctypes.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        _close_quietly(self)
 
     @staticmethod
     def _prep(poses, lights):
