@@ -18,7 +18,7 @@
  * independently against that text; this file is the checker.  It is never linked into the product.
  *
  * PARITY PIN STATUS: pinned against GL readbacks of the reference's own six shaders, executed headless by SwiftShader
- * (tests/gl_readback.py, fixtures tests/golden/gl_readback/, tests/test_gl_readback.py): 99.5 % of 142 M pixels in 177
+ * (tests/gl_readback.py, fixtures tests/golden/gl_readback/, tests/test_gl_readback.py): 99.5 % of 147 M pixels in 195
  * frames identical, every other pixel explained by a discontinuity GL leaves to the implementation (tests/gl_census.py);
  * plus analytic KATs (tests/test_kat_analytic.py) and golden digests (tests/golden/).
  */

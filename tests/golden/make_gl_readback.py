@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import gl_census  # noqa: E402
 import gl_readback  # noqa: E402
 from oracle import raster, wad_oracle  # noqa: E402
-from util import GOLDEN, META_PATH, ensure_big_wad, ensure_wad  # noqa: E402
+from util import GOLDEN, META_PATH, ROOT, ensure_big_wad, ensure_wad  # noqa: E402
 
 OUT = os.path.join(GOLDEN, 'gl_readback')
 
@@ -113,15 +113,45 @@ def bench_pose(width, height, index=0):
 _BUILT = {}
 
 
-def sweep_pose(index, width, height, i, time=0.0, big=False):
-    """pose i of the benchmark sweep (rust-doom_amd/sharding.py: pose_sweep) of level `index` of the synthetic IWAD, or of
-    the 10 x E1M1 level (big: the MAP29 stand-in), at `time`"""
+OTHER_SEEDS = (7, 4242, 90210)   # tests/test_other_seeds.py
+
+
+def other_seed_wad(seed):
+    """an IWAD from another seed of tools/mkwad.py with three small random levels (tests/test_other_seeds.py writes the same)"""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import mkwad
+    path = os.path.join(tempfile.gettempdir(), 'rdoom_other_seed_%d.wad' % seed)
+    if not os.path.exists(path):
+        rng = np.random.RandomState(seed)
+        specs = [('E1M%d' % (k + 1), ('gen', seed * 31 + k, int(rng.randint(24, 41)), int(rng.randint(4, 10)))) for k in range(3)]
+        data, _ = mkwad.build_wad(seed, specs=specs)
+        tmp = '%s.%d.tmp' % (path, os.getpid())
+        with open(tmp, 'wb') as f:
+            f.write(data)
+        os.replace(tmp, path)
+    return path
+
+
+def wad_of(key):
+    """level key -> (IWAD path, level index): an index of the synthetic IWAD, 'big', or 'seed<S>:<index>'"""
+    if key == 'big':
+        return ensure_big_wad(), 0
+    if isinstance(key, str) and key.startswith('seed'):
+        seed, index = key[4:].split(':')
+        return other_seed_wad(int(seed)), int(index)
+    return ensure_wad(), key
+
+
+def sweep_pose(key, width, height, i, time=0.0):
+    """pose i of the benchmark sweep (rust-doom_amd/sharding.py: pose_sweep) of the level `key` names (wad_of), at `time`"""
     import importlib
     import rust_doom_amd as rd
     sharding = importlib.import_module('rust-doom_amd.sharding')
-    if (index, big) not in _BUILT:
-        _BUILT[(index, big)] = rd.Wad(ensure_big_wad() if big else ensure_wad(), META_PATH).build_level(index)
-    p = sharding.pose_sweep(rd, _BUILT[(index, big)], 1, width, height, first=i, time=time)[0]
+    if key not in _BUILT:
+        path, index = wad_of(key)
+        _BUILT[key] = rd.Wad(path, META_PATH).build_level(index)
+    p = sharding.pose_sweep(rd, _BUILT[key], 1, width, height, first=i, time=time)[0]
     out = np.zeros(33, np.float32)
     out[:16], out[16:32], out[32] = p['modelview'], p['projection'], p['time']
     return out
@@ -141,7 +171,13 @@ def extended_frames():
     for index, i, t in ((2, 5, 2.3), (2, 517, 6.9), (0, 261, 12.4), (0, 773, 0.0)):
         out.append(('L%d_sweep%d_t%.1f_2160p' % (index, i, t), index, 3840, 2160, sweep_pose(index, 3840, 2160, i, time=t), None))
     # the 10 x E1M1 level (38 k triangles: the MAP29 stand-in)
-    out += [('big_sweep%d_1080p' % i, 'big', 1920, 1080, sweep_pose(0, 1920, 1080, i, big=True), None) for i in (3, 259, 515, 771)]
+    out += [('big_sweep%d_1080p' % i, 'big', 1920, 1080, sweep_pose('big', 1920, 1080, i), None) for i in (3, 259, 515, 771)]
+    # IWADs from other seeds of the generator: other textures, other atlas packings, other maps
+    for seed in OTHER_SEEDS:
+        for index in range(3):
+            key = 'seed%d:%d' % (seed, index)
+            out += [('seed%d_L%d_sweep%d_t%.1f_640' % (seed, index, i, t), key, 640, 400, sweep_pose(key, 640, 400, i, time=t), None)
+                    for i, t in ((11, 0.0), (523, 5.3))]
     return out
 
 
@@ -158,7 +194,8 @@ def extended_census(lv, glref, oracle, pose, w, h, obj_seed=None):
 
 def extended_level(levels, key):
     if key not in levels:
-        levels[key] = wad_oracle.build_level(ensure_big_wad() if key == 'big' else ensure_wad(), META_PATH, 0 if key == 'big' else key)
+        path, index = wad_of(key)
+        levels[key] = wad_oracle.build_level(path, META_PATH, index)
     return levels[key]
 
 
@@ -199,7 +236,7 @@ def main():
     print('total', tot, 'mismatch fraction %.4f' % (tot['mismatch'] / tot['pixels']))
     # Extended census: counts only (no readbacks are stored for these frames), a wider net for systematic differences --
     # every 32nd pose of the benchmark sweep at 1920x1080, eight poses of each other level's sweep at 640x400, time-varying
-    # frames with displaced doors / lifts on every level, 3840x2160 frames, the 10 x E1M1 level.
+    # frames with displaced doors / lifts on every level, 3840x2160 frames, the 10 x E1M1 level, IWADs from other seeds.
     census['extended'] = {}
     for key, index, w, h, pose, obj_seed in extended_frames():
         lv = extended_level(levels, index)

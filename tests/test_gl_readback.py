@@ -6,10 +6,10 @@ Committed under tests/golden/gl_readback/ (generator: tests/golden/make_gl_readb
 primitive SwiftShader's rasteriser chose per pixel, and the mismatch census of the oracle's frames against them --
 46 frames: the 27 golden poses at 320x200 (level 0 pose 0 = BASELINE config 2: E1M1, spawn pose, 320x200), three frames
 with moving objects, twelve targeted views (sky, decorations, scrolling / animated textures), poses 0, 341, 682 and 1000 of
-the benchmark sweep at 1920x1080.  An EXTENDED census (counts only, no stored readbacks, 131 M pixels in 131 frames: 32
+the benchmark sweep at 1920x1080.  An EXTENDED census (counts only, no stored readbacks, 136 M pixels in 149 frames: 32
 more poses of that sweep at 1920x1080, eight poses of every other level at 640x400, three time-varying frames per level
-with every door / lift displaced, four 3840x2160 frames, four frames of the 10 x E1M1 level) widens the net for
-systematic differences.
+with every door / lift displaced, four 3840x2160 frames, four frames of the 10 x E1M1 level, eighteen frames of IWADs
+written from other seeds) widens the net for systematic differences.
 
 What is asserted:
   * every mismatching pixel is explained by a discontinuity GL leaves to the implementation (tests/gl_census.py):
@@ -19,7 +19,7 @@ What is asserted:
     regenerated from the reference's shader files and must equal the committed ones;
   * (gpu) the HIP renderer's frames have exactly the oracle's mismatch sets against the GL readbacks.
 
-Bounds (measured: 0.84 % of the 10 982 400 stored pixels and 0.43 % of the 131 123 200 extended ones differ; 95 % of those
+Bounds (measured: 0.84 % of the 10 982 400 stored pixels and 0.44 % of the 135 731 200 extended ones differ; 95 % of those
 are texel-boundary picks caused by SwiftShader's ~13-bit perspective interpolation, 2.4 % lie on primitive edges; winners
 differ on 0.03 - 0.05 %):"""
 import importlib.util
@@ -69,7 +69,7 @@ def mismatch_counts(lv, key, fb, prim):
 def test_extended_census_is_clean_and_bounded():
     tot = CENSUS['extended_total']
     assert tot['other'] == 0 and all(f['other'] == 0 for f in CENSUS['extended'].values())
-    assert tot['pixels'] >= 130_000_000 and len(CENSUS['extended']) >= 131
+    assert tot['pixels'] >= 135_000_000 and len(CENSUS['extended']) >= 149
     assert tot['mismatch'] <= MAX_MISMATCH_TOTAL * tot['pixels'], tot
     assert tot['winner_mismatch'] <= MAX_WINNER_MISMATCH_TOTAL * tot['pixels'], tot
     for k, f in CENSUS['extended'].items():
@@ -78,7 +78,7 @@ def test_extended_census_is_clean_and_bounded():
         assert f['mismatch'] - f['depth tie'] <= MAX_MISMATCH_FRAME * f['pixels'], (k, f)
         assert sum(f[c] for c in gl_census.CLASSES) == f['mismatch'], k
     assert sum(1 for f in CENSUS['extended'].values() if f['width'] == 1920) >= 32
-    assert {f['level'] for f in CENSUS['extended'].values()} == set(range(9)) | {'big'}
+    assert {f['level'] for f in CENSUS['extended'].values()} == set(range(9)) | {'big'} | {'seed%d:%d' % (s, i) for s in gen.OTHER_SEEDS for i in range(3)}
     assert sum(1 for f in CENSUS['extended'].values() if f['width'] == 3840) >= 4
     assert sum(1 for f in CENSUS['extended'].values() if f['objects_seed'] is not None and f['time'] > 0) >= 27
 
@@ -124,12 +124,13 @@ def test_swiftshader_runs_the_reference_shaders(oracle_levels, key):
 
 
 @pytest.mark.skipif(not gl_readback.available(), reason='needs SwiftShader and the reference checkout (/root/reference)')
-@pytest.mark.parametrize('key', ['L0_bench624_1080p', 'L5_sweep128_640', 'L3_sweep424_t12.1_objects_640', 'L7_sweep808_t34.5_objects_640'])
-def test_swiftshader_extended_census(oracle_levels, key):
+@pytest.mark.parametrize('key', ['L0_bench624_1080p', 'L5_sweep128_640', 'L3_sweep424_t12.1_objects_640', 'L7_sweep808_t34.5_objects_640',
+                                 'seed4242_L0_sweep523_t5.3_640'])
+def test_swiftshader_extended_census(key):
     """regenerates the counts of extended frames (nothing stored but the counts) from the reference's shader files"""
     c = CENSUS['extended'][key]
-    lv = oracle_levels(c['level'])
-    _k, _i, w, h, pose, seed = [f for f in gen.extended_frames() if f[0] == key][0]
+    _k, level_key, w, h, pose, seed = [f for f in gen.extended_frames() if f[0] == key][0]
+    lv = gen.extended_level({}, level_key)
     got = gen.extended_census(lv, gl_readback.GLReference(lv), raster.RasterOracle(lv), pose, w, h, seed)
     assert got['other'] == 0
     for k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES:
