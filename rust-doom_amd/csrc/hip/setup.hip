@@ -412,6 +412,33 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
       float wkey;
       (void)setup_triangle(lv, pc, objs, t, tri, width, height, kinds_mask, rec.r, rec.s, wkey);  // visible: the cull kernel said so
       bucket = depth_bucket(wkey);
+#ifndef RDOOM_NO_EMPTY_CULL
+      // A triangle whose bbox holds at most 3 x 3 pixel centres and covers none of them (the rasteriser's own edge
+      // functions, operation order and fill rule: R1, R2) draws nothing: its bbox is made empty, so the binning kernel
+      // lists it in no tile (far geometry at small frame sizes: most of the visible triangles are of this kind).
+      {
+        const int bx0 = (int)(rec.r.bb0 & 0xFFFFu), by0 = (int)(rec.r.bb0 >> 16), bx1 = (int)(rec.r.bb1 & 0xFFFFu),
+                  by1 = (int)(rec.r.bb1 >> 16);
+        if (bx1 - bx0 <= 2 && by1 - by0 <= 2) {
+          const bool tl0 = (rec.r.flags & (1u << 24)) != 0u, tl1 = (rec.r.flags & (1u << 25)) != 0u, tl2 = (rec.r.flags & (1u << 26)) != 0u;
+          bool any = false;
+#pragma unroll
+          for (int iy = 0; iy < 3; iy++) {
+            const float py = (float)(by0 + iy) + 0.5f;
+            const float t0 = fmaf(rec.r.e[1], py, rec.r.e[2]), t1 = fmaf(rec.r.e[4], py, rec.r.e[5]), t2 = fmaf(rec.r.e[7], py, rec.r.e[8]);
+#pragma unroll
+            for (int ix = 0; ix < 3; ix++) {
+              const float px = (float)(bx0 + ix) + 0.5f;
+              const float e0 = fmaf(rec.r.e[0], px, t0), e1 = fmaf(rec.r.e[3], px, t1), e2 = fmaf(rec.r.e[6], px, t2);
+              const bool in = ((e0 > 0.0f) | ((e0 == 0.0f) & tl0)) & ((e1 > 0.0f) | ((e1 == 0.0f) & tl1)) &
+                              ((e2 > 0.0f) | ((e2 == 0.0f) & tl2));
+              any |= in & (bx0 + ix <= bx1) & (by0 + iy <= by1);
+            }
+          }
+          if (!any) rec.r.bb0 = 0x0000FFFFu, rec.r.bb1 = 0u;  // x0 = 65535 > x1 = 0
+        }
+      }
+#endif
       lrank = atomicAdd(&lcount[bucket], 1u);
     }
     __syncthreads();
