@@ -23,7 +23,7 @@ struct DebugOptions {
   int no_cover = 0;      // no depth-only body for quadrant-covering triangles
   int raster_stats = 0;  // census of the rasteriser's paths on stderr (instrumented instantiation: slower)
 };
-DebugOptions &debug_options();
+DebugOptions debug_options();  // a snapshot taken under the lock rdoom_debug_set writes under (one host thread per GPU may render while a test thread sets hooks)
 inline rdoom_status fail(rdoom_status code, const char *fmt, ...) {
   char buf[512];
   va_list ap;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -191,10 +192,16 @@ bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint
   const int bt = bin_threads == 512 ? 512 : (bin_threads == 128 ? 128 : 256);
   // LDS budget: the kernel's static arrays plus two counters per tile must fit the 64 KiB a workgroup may use; frames
   // with more tiles than that (beyond ~5 900: 7680x4320 and up) are rasterised from the sorted list instead
-  hipFuncAttributes attr;
-  if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(bk)) != hipSuccess ||
-      attr.sharedSizeBytes + 2 * sizeof(uint32_t) * bin_tiles > 65536u || (uint32_t)(tiles_x * tiles_y) > MAX_TILES)
-    return false;
+  static std::atomic<size_t> static_lds[3];  // per variant, asked once (a constant of the compiled kernel); 0 = not asked yet
+  std::atomic<size_t> &slot = static_lds[bin_threads == 512 ? 2 : (bin_threads == 128 ? 1 : 0)];
+  size_t lds = slot.load(std::memory_order_relaxed);
+  if (lds == 0) {
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(bk)) != hipSuccess) return false;
+    lds = attr.sharedSizeBytes + 1;
+    slot.store(lds, std::memory_order_relaxed);
+  }
+  if ((lds - 1) + 2 * sizeof(uint32_t) * bin_tiles > 65536u || (uint32_t)(tiles_x * tiles_y) > MAX_TILES) return false;
   hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bt), 2 * sizeof(uint32_t) * bin_tiles, st, recs, sorted, counts, cap, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, hits, overflow);
   return true;

@@ -18,7 +18,8 @@ constexpr uint32_t MAX_TILES = 8192;     // tiles per frame the binning kernel k
 // Kernel 1: vertex stage, triangle setup, near-to-far record order (setup.hip)
 rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
                           const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
-                          TriRec *recs, uint32_t *visible, uint4 *sorted, uint32_t *counts, uint32_t *ghist, uint32_t cap);
+                          TriRec *recs, uint32_t *visible, uint4 *sorted, uint32_t *counts, uint32_t *ghist, uint32_t cap,
+                          uint32_t *mismatch_flag);  // set when the set-up kernel rejects a triangle the cull kernel kept
 size_t setup_histogram_bytes(uint32_t max_poses);  // scratch of the counting sort (per pose: one counter per depth bucket)
 // Kernel 1b: per-tile triangle lists (bin.hip).  false = the frame has too many tiles for the kernel's LDS counters:
 // nothing was launched and the caller must flag every pose as "bins incomplete"

@@ -409,7 +409,9 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       best_d[k] = NONE;
       best_r[k] = NONE;
     }
-    uint32_t lane_far = NONE;  // max of best_d: the farthest depth this lane still holds
+    // max of best_d: the farthest depth this lane still holds.  A lane whose block lies outside the frame (partial tiles:
+    // the bottom row at 1080 = 16 * 64 + 56) stores nothing and must not keep the wave-wide farthest depth at "none"
+    uint32_t lane_far = ((bx >= width) | (by >= height)) ? 0u : NONE;
 #pragma unroll 1
     for (uint32_t base = 0; base < count; base += 64u) {
       if (!single) gather(base);

@@ -44,7 +44,8 @@ struct rdoom_batch {
   uint2 *d_hits = nullptr;         // per pose: entry_cap (entry, tile) pairs: the binning kernel's count pass -> its fill pass
   uint32_t *d_overflow = nullptr;  // per pose: 1 = bins incomplete, rasteriser scans the sorted list
   uint32_t entry_cap = 0, n_tiles = 0;
-  uint32_t *d_fix_count = nullptr;  // [0] = queued pixels, [1] = error flag (fixup list overflow)
+  uint32_t *d_fix_count = nullptr;  // [0] = queued pixels, [1] = error flag (fixup list overflow), [2] = error flag (the set-up kernel
+                                    // disagreed with the cull kernel about a triangle: the counting sort's buckets would not add up)
   uint2 *d_fix_list = nullptr;
   uint32_t fix_cap = 1u << 20;
   uint32_t *d_counts = nullptr, *d_vis = nullptr, *d_prim = nullptr;
@@ -61,6 +62,20 @@ struct rdoom_batch {
   bool vis16 = false;  // record indices fit 16 bits: visibility words are u16
   float *d_ndc = nullptr;  // (ix + 0.5) / (width / 2) - 1 for every column, then (iy + 0.5) / (height / 2) - 1 for every row
 };
+
+// Every entry point that touches a batch's memory or waits for its work first makes the level's device current: a host
+// thread that drives several GPUs (or read another batch in between) would otherwise synchronise / copy on the wrong one.
+static hipError_t bind_device(const rdoom_batch *b) { return hipSetDevice(b->level->device); }
+
+// What only the device finds out about a render: read after a synchronisation, reported as a status.
+static rdoom_status device_flags(const rdoom_batch *b, uint32_t *out_fixups = nullptr) {
+  uint32_t fix[3] = {0, 0, 0};
+  HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
+  if (out_fixups) *out_fixups = fix[0];
+  if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
+  if (fix[2]) return rdoom::fail(RDOOM_HIP_ERROR, "internal: set-up and cull kernels disagree about a triangle (build flags changed?)");
+  return RDOOM_OK;
+}
 
 extern "C" {
 
@@ -350,7 +365,7 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_entries, sizeof(uint32_t) * (size_t)b->entry_cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_hits, sizeof(uint2) * (size_t)b->entry_cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_overflow, sizeof(uint32_t) * max_poses);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_count, 2 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_count, 3 * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_list, sizeof(uint2) * (size_t)b->fix_cap);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_ghist, setup_histogram_bytes(max_poses));
@@ -436,10 +451,11 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
                            hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(b->ev_copy, st));
   const int W = (int)b->width, H = (int)b->height;
+  HIP_TRY(hipMemsetAsync(b->d_fix_count + 2, 0, sizeof(uint32_t), st));
   if (lv->ntri)
     if (rdoom_status rs = launch_setup(st, n, lv->view, b->d_poses, object_modelviews ? (const ObjectConst *)b->d_objects : nullptr,
                                        lv->n_objects, W, H, kinds_mask, b->d_recs, b->d_visible, b->d_sorted, b->d_counts,
-                                       b->d_ghist, b->cap))
+                                       b->d_ghist, b->cap, b->d_fix_count + 2))
       return rs;
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   if (!(lv->ntri && !rdoom::debug_options().no_bins &&
@@ -476,10 +492,10 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     HIP_TRY(hipMemcpy(counts.data(), b->d_counts, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
     tm->visible_triangles = 0;
     for (uint32_t c : counts) tm->visible_triangles += c;
-    uint32_t fix[2] = {0, 0};
-    HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
-    tm->fixup_pixels = fix[0];
-    if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
+    uint32_t fixups = 0;
+    const rdoom_status fs = device_flags(b, &fixups);
+    tm->fixup_pixels = fixups;
+    if (fs) return fs;
   }
   return RDOOM_OK;
 }
@@ -506,8 +522,10 @@ rdoom_status rdoom_batch_collect_timings(rdoom_batch *b, rdoom_timings *out, uin
   *out = rdoom_timings{};
   if (out_renders) *out_renders = b->ring_n;
   if (b->ring_n == 0) return RDOOM_OK;
-  HIP_TRY(hipSetDevice(b->level->device));
-  HIP_TRY(hipEventSynchronize(b->ring[b->ring_n - 1][3]));
+  HIP_TRY(bind_device(b));
+  // profiled renders may have been queued on several streams (bench.py --streams): nothing orders an earlier slot's
+  // events against the last one's, so every slot's closing event is waited for
+  for (uint32_t i = 0; i < b->ring_n; i++) HIP_TRY(hipEventSynchronize(b->ring[i][3]));
   for (uint32_t i = 0; i < b->ring_n; i++) {
     float a = 0, r = 0, f = 0, t = 0;
     HIP_TRY(hipEventElapsedTime(&a, b->ring[i][0], b->ring[i][1]));
@@ -520,12 +538,11 @@ rdoom_status rdoom_batch_collect_timings(rdoom_batch *b, rdoom_timings *out, uin
   std::vector<uint32_t> counts(b->last_n);  // of the last render
   HIP_TRY(hipMemcpy(counts.data(), b->d_counts, sizeof(uint32_t) * b->last_n, hipMemcpyDeviceToHost));
   for (uint32_t c : counts) out->visible_triangles += c;
-  uint32_t fix[2] = {0, 0};
-  HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
-  out->fixup_pixels = fix[0];
+  uint32_t fixups = 0;
+  const rdoom_status fs = device_flags(b, &fixups);
+  out->fixup_pixels = fixups;
   b->ring_n = 0, b->ring_poses = 0;
-  if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
-  return RDOOM_OK;
+  return fs;
 }
 
 rdoom_status rdoom_batch_render_objects(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
@@ -544,12 +561,9 @@ rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out) {
 
 rdoom_status rdoom_batch_finish(rdoom_batch *b) {
   if (!b) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
-  HIP_TRY(hipSetDevice(b->level->device));
+  HIP_TRY(bind_device(b));
   HIP_TRY(hipDeviceSynchronize());
-  uint32_t fix[2] = {0, 0};
-  HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
-  if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
-  return RDOOM_OK;
+  return device_flags(b);
 }
 
 rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **out_device_ptr) {
@@ -562,16 +576,16 @@ rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *b, uint32_t first, uint32
   if (!b || !host_out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   if ((uint64_t)first + count > b->last_n) return rdoom::fail(RDOOM_BAD_ARG, "frame range outside the last render");
   const size_t frame = (size_t)b->width * b->height;
+  HIP_TRY(bind_device(b));
   HIP_TRY(hipDeviceSynchronize());
-  uint32_t fix[2] = {0, 0};
-  HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
-  if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
+  if (rdoom_status fs = device_flags(b)) return fs;
   HIP_TRY(hipMemcpy(host_out, b->d_fb + frame * first, frame * count, hipMemcpyDeviceToHost));
   return RDOOM_OK;
 }
 
 rdoom_status rdoom_batch_enable_primitive_ids(rdoom_batch *b) {
   if (!b) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  HIP_TRY(bind_device(b));  // the ids live next to the batch's other scratch, on the level's device
   if (!b->d_prim) {
     const size_t npx = (size_t)b->width * b->height * b->max_poses;
     HIP_TRY(hipMalloc((void **)&b->d_prim, sizeof(uint32_t) * npx));
@@ -587,6 +601,7 @@ rdoom_status rdoom_batch_read_primitive_ids(rdoom_batch *b, uint32_t first, uint
     return rdoom::fail(RDOOM_BAD_ARG, "primitive ids are not captured: call rdoom_batch_enable_primitive_ids, then render");
   if ((uint64_t)first + count > b->last_n) return rdoom::fail(RDOOM_BAD_ARG, "frame range outside the last render");
   const size_t frame = (size_t)b->width * b->height;
+  HIP_TRY(bind_device(b));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(host_out, b->d_prim + frame * first, frame * count * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return RDOOM_OK;

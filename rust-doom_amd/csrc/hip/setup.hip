@@ -386,7 +386,8 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
                                                     int width, int height, uint32_t kinds_mask,
                                                     const uint32_t *__restrict__ visible, TriRec *__restrict__ recs,
                                                     uint4 *__restrict__ sorted, const uint32_t *__restrict__ counts,
-                                                    uint32_t *__restrict__ ghist, uint32_t cap) {
+                                                    uint32_t *__restrict__ ghist, uint32_t cap,
+                                                    uint32_t *__restrict__ mismatch_flag) {
   const uint32_t pose = blockIdx.y, n = counts[pose];
   const PoseConst &pc = poses[pose];
   const ObjectConst *objs = objects ? objects + (size_t)pose * n_objects : nullptr;
@@ -410,7 +411,10 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
       const uint32_t t = pvisible[i];
       const LevelTri tri = lv.tris[t];
       float wkey;
-      (void)setup_triangle(lv, pc, objs, t, tri, width, height, kinds_mask, rec.r, rec.s, wkey);  // visible: the cull kernel said so
+      // visible: the cull kernel said so, with the same operations (-ffp-contract=off, every deciding product an explicit
+      // fmaf), and counted this bucket.  Should a build ever break that, the histogram's runs no longer add up: flagged,
+      // and reported by rdoom_batch_finish / the read functions instead of drawing from overwritten records.
+      if (!setup_triangle(lv, pc, objs, t, tri, width, height, kinds_mask, rec.r, rec.s, wkey)) *mismatch_flag = 1u;
       bucket = depth_bucket(wkey);
 #ifndef RDOOM_NO_EMPTY_CULL
       // A triangle whose bbox holds at most 3 x 3 pixel centres and covers none of them (the rasteriser's own edge
@@ -462,7 +466,8 @@ __global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const Po
 
 rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
                           const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
-                          TriRec *recs, uint32_t *visible, uint4 *sorted, uint32_t *counts, uint32_t *ghist, uint32_t cap) {
+                          TriRec *recs, uint32_t *visible, uint4 *sorted, uint32_t *counts, uint32_t *ghist, uint32_t cap,
+                          uint32_t *mismatch_flag) {
   HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_poses, st));
   HIP_TRY(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * SORT_BUCKETS * (size_t)n_poses, st));
   // several workgroups per pose on large levels (each takes a share of the clusters): one would walk them serially
@@ -472,7 +477,7 @@ rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelVie
   hipLaunchKernelGGL(sort_scan_kernel, dim3(n_poses), dim3(256), 0, st, ghist);
   const uint32_t place_groups = std::min<uint32_t>((cap + 1023u) / 1024u, 16u);  // about a fifth of a level is visible: one or two chunks of 256 records each
   hipLaunchKernelGGL(setup_kernel, dim3(place_groups, n_poses), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,
-                     kinds_mask, visible, recs, sorted, counts, ghist, cap);
+                     kinds_mask, visible, recs, sorted, counts, ghist, cap, mismatch_flag);
   return RDOOM_OK;
 }
 

@@ -1,6 +1,7 @@
 // C ABI pieces that do not belong to a subsystem: last-error storage and the camera helper.
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #include "../common.hpp"
 
@@ -9,9 +10,13 @@ std::string &last_error_ref() {
   static thread_local std::string err;
   return err;
 }
-DebugOptions &debug_options() {
-  static DebugOptions opts;
-  return opts;
+namespace {
+std::mutex g_debug_mutex;
+DebugOptions g_debug_options;
+}  // namespace
+DebugOptions debug_options() {
+  std::lock_guard<std::mutex> lock(g_debug_mutex);
+  return g_debug_options;
 }
 }  // namespace rdoom
 
@@ -19,7 +24,8 @@ extern "C" {
 
 rdoom_status rdoom_debug_set(const char *name, int32_t value) {
   if (!name) return rdoom::fail(RDOOM_BAD_ARG, "name is null");
-  rdoom::DebugOptions &o = rdoom::debug_options();
+  std::lock_guard<std::mutex> lock(rdoom::g_debug_mutex);
+  rdoom::DebugOptions &o = rdoom::g_debug_options;
   const struct {
     const char *name;
     int *field;
