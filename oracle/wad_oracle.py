@@ -146,9 +146,13 @@ class Archive:
     def __init__(self, wad_path, meta_path):
         with open(wad_path, 'rb') as f:
             self.data = f.read()
+        if len(self.data) < 12:
+            raise WadError('bad wad header')
         ident, num_lumps, table = struct.unpack_from('<4sii', self.data, 0)
         if ident != b'IWAD':  # archive.rs:69-72
             raise WadError('bad wad header identifier')
+        if num_lumps < 0 or table < 0 or table + 16 * num_lumps > len(self.data):
+            raise WadError('bad lump info table')  # archive.rs:78-83: the reads of the table fail (bad_lump_info)
         self.lumps, self.index_map, self.levels = [], {}, []
         for i in range(num_lumps):  # archive.rs:80-98
             pos, size, raw = struct.unpack_from('<ii8s', self.data, table + 16 * i)
@@ -160,8 +164,17 @@ class Archive:
                 self.levels.append(i - 1)
         self.meta = Metadata(meta_path)
 
-    def lump_bytes(self, index):
+    def _range(self, index):
+        """LumpReader::read (archive.rs:244-257): a lump is sought and read when asked for -- an entry that points outside
+        the file is an I/O error then, and only then (file_pos / size are i32 in the file, taken as unsigned)"""
         name, pos, size = self.lumps[index]
+        pos, size = pos & 0xFFFFFFFF, size & 0xFFFFFFFF
+        if size > 0 and pos + size > len(self.data):
+            raise WadError('reading lump %r failed: outside the file' % (name,))
+        return (0 if size == 0 else pos), size
+
+    def lump_bytes(self, index):
+        pos, size = self._range(index)
         return self.data[pos:pos + size]
 
     def named(self, name):
@@ -175,7 +188,8 @@ class Archive:
         return i
 
     def decode_vec(self, index, fmt):  # archive.rs:172-190
-        name, pos, size = self.lumps[index]
+        name = self.lumps[index][0]
+        pos, size = self._range(index)
         st = struct.Struct(fmt)
         if not (size > 0 and size % st.size == 0):
             raise WadError('bad lump size %s %d %d' % (name, size, st.size))
@@ -703,7 +717,7 @@ def _to_height(hdef, sector, heights):  # visitor.rs:273-286
         base = sector[1]
     else:
         raise WadError('bad height ref')
-    return base + hdef.get('off', 0)
+    return i16(base + hdef.get('off', 0))
 
 
 def _option_to_heights(edef, sector, heights):  # visitor.rs:288-301
@@ -748,6 +762,8 @@ class LevelAnalysis:
                 left = level.side(ld[6])
                 if left is not None:
                     sid = level.sidedefs[left][5]
+                    if sid >= len(level.sectors):
+                        continue  # the reference indexes level.sectors[sid] (visitor.rs:175, a panic): defined as warn-and-skip
                     self._update(self.dynamic_info.setdefault(sid, DynamicSectorInfo()), next_id, level, sid, move)
                 continue
             if tag in first_index:
@@ -872,9 +888,15 @@ def points_to_polygon(points):  # visitor.rs:1192-1259
     return out
 
 
+def i16(x):
+    """WadCoord is i16 in the reference and its integer height arithmetic is plain `+` / `-`: an overflow wraps in a
+    release build (and panics in a debug build).  Defined here, as in the product, as the release behaviour."""
+    return ((int(x) + 32768) & 0xFFFF) - 32768
+
+
 def partition_line(node):  # visitor.rs:1150-1155
     return Line2f.from_two_points(from_wad_coords(node[0], node[1]),
-                                  from_wad_coords(node[0] + node[2], node[1] + node[3]))
+                                  from_wad_coords(i16(node[0] + node[2]), i16(node[1] + node[3])))
 
 
 class LevelWalker:
@@ -884,7 +906,7 @@ class LevelWalker:
         mn, mx = 32767, -32768  # visitor.rs:1173-1182
         for s in level.sectors:
             mn, mx = min(mn, s[0]), max(mx, s[1])
-        self.height_range = (mn - 512, mx + 512)
+        self.height_range = (i16(mn - 512), i16(mx + 512))
         self.bsp_lines = []
         self.light_cache = {}
 
@@ -987,11 +1009,11 @@ class LevelWalker:
         floor, ceiling = sector[0], sector[1]
         unpeg_lower = (line[2] & 0x10) != 0
         floor_id, ceiling_id, floor_range, ceiling_range = info
-        max_height = ceiling_range[1] - floor_range[0]
+        max_height = i16(ceiling_range[1] - floor_range[0])
         back_sid = lv.side_sector(lv.seg_back_sidedef(seg))
         if back_sid is None:
             self.wall_quad(sid, seg, vertices, floor_id if unpeg_lower else ceiling_id,
-                           (floor, floor + max_height) if unpeg_lower else (ceiling - max_height, ceiling),
+                           (floor, i16(floor + max_height)) if unpeg_lower else (i16(ceiling - max_height), ceiling),
                            sidedef[4], PEG_BOTTOM if unpeg_lower else PEG_TOP, True)
             if is_sky_flat(sector[3]):
                 self.sky_quad(ceiling_id, vertices, (ceiling, mx))
@@ -1007,7 +1029,7 @@ class LevelWalker:
             self.sky_quad(floor_id, vertices, (mn, floor))
         unpeg_upper = (line[2] & 0x08) != 0
         if binfo[2][1] > floor_range[0]:
-            self.wall_quad(sid, seg, vertices, binfo[0], (back_floor - binfo[2][1] + floor_range[0], back_floor),
+            self.wall_quad(sid, seg, vertices, binfo[0], (i16(back_floor - binfo[2][1] + floor_range[0]), back_floor),
                            sidedef[3], PEG_BOTTOM_LOWER if unpeg_lower else PEG_TOP, True)
             fl = back_floor
         else:
@@ -1048,9 +1070,9 @@ class LevelWalker:
         v2 = (v2[0] + bx, v2[1] + by)
         y_off = sidedef[1]
         if size is not None and peg == PEG_TOP_FLOAT:
-            lo, hi = from_wad_height(low + y_off), from_wad_height(low + int(size[1]) + y_off)
+            lo, hi = from_wad_height(i16(low + y_off)), from_wad_height(i16(low + i16(int(size[1])) + y_off))
         elif size is not None and peg == PEG_BOTTOM_FLOAT:
-            lo, hi = from_wad_height(high + y_off - int(size[1])), from_wad_height(high + y_off)
+            lo, hi = from_wad_height(i16(high + y_off - i16(int(size[1])))), from_wad_height(i16(high + y_off))
         else:
             lo, hi = from_wad_height(low), from_wad_height(high)
         light = self.light_info(sid)
@@ -1067,7 +1089,7 @@ class LevelWalker:
         elif peg == PEG_BOTTOM:
             t1, t2 = size[1], size[1] - height
         elif peg == PEG_BOTTOM_LOWER:
-            sh = F(sector[1] - sector[0])
+            sh = F(i16(sector[1] - sector[0]))
             t1, t2 = size[1] + sh, size[1] - height + sh
         else:
             t1, t2 = size[1], F(0.0)
@@ -1381,6 +1403,8 @@ def build_level(wad_path, meta_path, level_index):
     sky_img = tex.texture(sky['texture_name']) if sky else None
     out.sky_texture = sky_img.pixels if sky_img is not None else np.zeros((1, 1), np.uint16)
     out.palette = tex.palettes[0].copy()
+    if len(tex.colormaps) < 32:  # game_shaders.rs:123-131 asks build_palette_texture for maps 0..=31: the reference indexes past the end (a panic) -- defined here as a corrupt WAD
+        raise WadError('COLORMAP has fewer than 32 maps')
     out.colormap = tex.colormaps[:32].reshape(-1).copy()
     out.palette_texture = tex.build_palette_texture(0, 0, 32)
     b = Builder(flat_bounds, wall_bounds, decor_bounds)

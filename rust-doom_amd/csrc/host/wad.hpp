@@ -178,6 +178,7 @@ struct LumpInfo {
   WadName name;
   uint64_t offset;
   size_t size;
+  bool outside = false;  // the directory entry points outside the file: an error when (and only when) the lump is read
 };
 class Archive {
  public:
@@ -189,7 +190,9 @@ class Archive {
   const LumpInfo &lump(size_t index) const;                 // lump_by_index; throws on missing
   std::optional<size_t> named_lump(const WadName &n) const;  // archive.rs:129-139
   size_t required_named_lump(const char *name) const;        // archive.rs:118-127
-  const uint8_t *lump_data(size_t index) const { return data_.data() + lumps_[index].offset; }
+  // LumpReader::read (archive.rs:244-257): the reference seeks and reads a lump when it is asked for, so a directory entry
+  // that points outside the file fails THEN (ErrorKind::Io, errors.rs:87-93) -- never for a lump nobody reads
+  const uint8_t *lump_data(size_t index) const;
   // LumpReader::decode_vec (archive.rs:172-190): size must be a positive multiple of `record`
   size_t checked_count(size_t index, size_t record) const;
 

@@ -83,8 +83,8 @@ std::unique_ptr<Archive> Archive::open(const std::string &wad_path, const std::s
     li.name = WadName::from_bytes(e + 8, 8);
     li.offset = (uint64_t)(uint32_t)rd_i32(e);
     li.size = (size_t)(uint32_t)rd_i32(e + 4);
-    if (li.size > 0 && li.offset + li.size > d.size()) throw WadError(RDOOM_CORRUPT_WAD, "lump outside file");
-    if (li.size == 0) li.offset = 0;
+    li.outside = li.size > 0 && li.offset + li.size > d.size();  // reported when the lump is read (lump_data)
+    if (li.size == 0 || li.outside) li.offset = 0;
     a->index_map_[li.name] = a->lumps_.size();  // last duplicate wins (archive.rs:85)
     a->lumps_.push_back(li);
     if (li.name == WadName::from_str("THINGS")) {
@@ -99,6 +99,12 @@ std::unique_ptr<Archive> Archive::open(const std::string &wad_path, const std::s
 size_t Archive::level_lump_index(size_t level) const {
   if (level >= levels_.size()) throw WadError(RDOOM_BAD_ARG, "level index out of range");
   return levels_[level];
+}
+
+const uint8_t *Archive::lump_data(size_t index) const {
+  const LumpInfo &li = lump(index);
+  if (li.outside) throw WadError(RDOOM_IO, "reading lump " + li.name.str() + " failed: it lies outside the file");
+  return data_.data() + li.offset;
 }
 
 const LumpInfo &Archive::lump(size_t index) const {

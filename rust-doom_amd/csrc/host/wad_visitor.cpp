@@ -142,8 +142,11 @@ LevelAnalysis::LevelAnalysis(const Level &level, const WadMetadata &meta) {
     const std::optional<MoveEffectDef> &move = it != meta.linedef.end() ? it->second.move_effect : none;
     num_triggers_++;
     if (ld.sector_tag == 0) {  // manual linedef: acts on its left sector (visitor.rs:385-404)
+      // (a left side naming a sector that does not exist: the reference indexes level.sectors[id], visitor.rs:175 -- a
+      // panic; defined here as the warn-and-skip the walker applies to every other dangling reference)
       if (const WadSidedef *left = level.side(ld.left_side))
-        update_dynamic(dynamic_info_[left->sector], next_id, level, left->sector, move);
+        if (left->sector < level.sectors.size())
+          update_dynamic(dynamic_info_[left->sector], next_id, level, left->sector, move);
       continue;
     }
     auto first = std::lower_bound(tags.begin(), tags.end(), std::make_pair(ld.sector_tag, (uint16_t)0));

@@ -1,0 +1,386 @@
+"""The product's HOST half (csrc/host/*.cpp: IWAD reader, textures, metadata, LevelAnalysis, LevelWalker, Builder -- SURVEY
+8(a) rows a1-a16) under -fsanitize=address,undefined on a corpus of MALFORMED IWADs ("race detection /
+sanitizers"; round 1's advisor found a content-driven out-of-bounds write in this code).
+
+The reference's behaviour on bad data is part of the path: structural errors fail with ErrorKind::CorruptWad / Io
+(wad/src/archive.rs:172-190 typed lump of a size that is zero or no multiple of the record; wad/src/errors.rs:9-19), but
+dangling references INSIDE a level are warned about and skipped, and the level is still built
+(wad/src/visitor.rs:599-604 child ids, 622-643 sub-sector / segs / sector, 658-664 seg vertices, 718-729 linedef /
+sidedef of a seg, 855-872 unknown texture / linedef / sidedef of a quad).  For every mutant:
+  * the sanitized build must neither crash nor report (exit code 0, nothing from ASan / UBSan on stderr);
+  * its outcome must be the numpy oracle's on the same file: the same status class (a WadError there <-> a negative status
+    here), or the same level -- every array, by CRC-32.
+The driver (tests/sanitize/host_driver.cpp) links the product's own host sources; g++ builds it on first use (~15 s)."""
+import glob
+import os
+import struct
+import subprocess
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from oracle import wad_oracle
+from util import META_PATH, ROOT
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, 'sanitize', '_build')
+DRIVER = os.path.join(BUILD, 'host_driver')
+LEVEL = 2   # E1M3 of the synthetic IWAD: 169 sub-sectors, doors, sky, decorations
+LEVEL_LUMPS = ['THINGS', 'LINEDEFS', 'SIDEDEFS', 'VERTEXES', 'SEGS', 'SSECTORS', 'NODES', 'SECTORS']
+RECORD = dict(THINGS=10, LINEDEFS=14, SIDEDEFS=30, VERTEXES=4, SEGS=12, SSECTORS=4, NODES=28, SECTORS=26)
+
+
+@pytest.fixture(scope='session')
+def driver():
+    host = os.path.join(ROOT, 'rust-doom_amd', 'csrc', 'host')
+    srcs = sorted(glob.glob(os.path.join(host, '*.cpp'))) + [os.path.join(HERE, 'sanitize', 'host_driver.cpp')]
+    deps = srcs + glob.glob(os.path.join(host, '*.hpp')) + [os.path.join(ROOT, 'include', 'rdoom.h'),
+                                                            os.path.join(ROOT, 'rust-doom_amd', 'csrc', 'common.hpp')]
+    if os.path.exists(DRIVER) and all(os.path.getmtime(d) <= os.path.getmtime(DRIVER) for d in deps):
+        return DRIVER
+    os.makedirs(BUILD, exist_ok=True)
+    flags = ['-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-ffp-contract=off',
+             '-I' + os.path.join(ROOT, 'include'), '-I' + host, '-I' + os.path.join(ROOT, 'rust-doom_amd', 'csrc')]
+
+    def cc(src):
+        obj = os.path.join(BUILD, os.path.basename(src) + '.o')
+        subprocess.check_call(['g++'] + flags + ['-c', src, '-o', obj])
+        return obj
+
+    with ThreadPoolExecutor(min(len(srcs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(cc, srcs))
+    subprocess.check_call(['g++', '-fsanitize=address,undefined'] + objs + ['-o', DRIVER])
+    return DRIVER
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class WadFile:
+    """directory + lump bytes of an IWAD, editable, written back with a layout of its own"""
+
+    def __init__(self, path):
+        raw = open(path, 'rb').read()
+        self.magic, n, off = struct.unpack_from('<4sii', raw, 0)
+        self.lumps = []
+        for i in range(n):
+            pos, size, name = struct.unpack_from('<ii8s', raw, off + 16 * i)
+            self.lumps.append([name, bytearray(raw[pos:pos + size])])
+
+    def level_lump(self, level, name):
+        markers = [i - 1 for i, (n, _) in enumerate(self.lumps) if n.rstrip(b'\0') == b'THINGS']
+        m = markers[level]
+        for k in range(1, 11):
+            if self.lumps[m + k][0].rstrip(b'\0') == name.encode():
+                return self.lumps[m + k]
+        raise KeyError(name)
+
+    def named(self, name):
+        for entry in self.lumps:
+            if entry[0].rstrip(b'\0') == name.encode():
+                return entry
+        raise KeyError(name)
+
+    def write(self, path, header_patch=None, dir_patch=None):
+        blob = bytearray(b'\0' * 12)
+        entries = []
+        for name, data in self.lumps:
+            entries.append((len(blob), len(data), name))
+            blob += data
+        dir_off = len(blob)
+        for i, (pos, size, name) in enumerate(entries):
+            if dir_patch and i in dir_patch:
+                pos, size = dir_patch[i](pos, size)
+            blob += struct.pack('<ii8s', pos, size, name)
+        struct.pack_into('<4sii', blob, 0, self.magic, len(entries), dir_off)
+        if header_patch:
+            header_patch(blob)
+        open(path, 'wb').write(bytes(blob))
+
+
+def _set(lump, record, index, fmt, offset, value):
+    struct.pack_into(fmt, lump[1], index * record + offset, value)
+
+
+def mutations():
+    """(name, function(WadFile) -> kwargs for write())"""
+    out = []
+
+    def add(name):
+        def deco(f):
+            out.append((name, f))
+            return f
+        return deco
+
+    # ---- structural: typed lumps of a bad size (archive.rs:172-190) -------------------------------------------------
+    for lump in LEVEL_LUMPS:
+        def trunc(w, lump=lump):
+            entry = w.level_lump(LEVEL, lump)
+            del entry[1][-1:]
+        out.append(('truncated_' + lump, trunc))
+
+        def empty(w, lump=lump):
+            w.level_lump(LEVEL, lump)[1][:] = b''
+        out.append(('empty_' + lump, empty))
+
+    # ---- dangling references inside the level: warn and skip --------------------------------------------------------
+    @add('node_child_subsector_out_of_range')
+    def _(w):
+        nodes = w.level_lump(LEVEL, 'NODES')
+        _set(nodes, 28, 3, '<H', 24, 0x8000 | 0x7FF0)   # right child: a leaf that does not exist
+        _set(nodes, 28, 5, '<H', 26, 0x8000 | 0x7000)
+
+    @add('node_child_node_out_of_range')
+    def _(w):
+        nodes = w.level_lump(LEVEL, 'NODES')
+        _set(nodes, 28, 7, '<H', 24, 0x7FF0)
+        _set(nodes, 28, 2, '<H', 26, 0x6000)
+
+    @add('ssector_segs_out_of_range')
+    def _(w):
+        ss = w.level_lump(LEVEL, 'SSECTORS')
+        _set(ss, 4, 10, '<H', 2, 0xFFF0)                # first seg beyond the lump
+        _set(ss, 4, 11, '<H', 0, 0x7000)                # count runs past the end
+        _set(ss, 4, 12, '<H', 0, 0)                     # zero segs
+
+    @add('seg_linedef_out_of_range')
+    def _(w):
+        segs = w.level_lump(LEVEL, 'SEGS')
+        for i in (0, 17, 40, 41):
+            _set(segs, 12, i, '<H', 6, 0xFFF0)
+
+    @add('seg_vertices_out_of_range')
+    def _(w):
+        segs = w.level_lump(LEVEL, 'SEGS')
+        _set(segs, 12, 5, '<H', 0, 0xFFF0)
+        _set(segs, 12, 30, '<H', 2, 0xFFF1)
+
+    @add('linedef_sidedefs_missing')
+    def _(w):
+        ld = w.level_lump(LEVEL, 'LINEDEFS')
+        for i in (0, 9):
+            _set(ld, 14, i, '<H', 10, 0xFFFF)           # no right side at all
+        for i in (3, 21, 50):
+            _set(ld, 14, i, '<H', 10, 0xFFF0)           # right side out of range
+        for i in (4, 22):
+            _set(ld, 14, i, '<H', 12, 0xFFF0)           # left side out of range
+
+    @add('two_sided_lines_lose_their_back_side')
+    def _(w):
+        ld = w.level_lump(LEVEL, 'LINEDEFS')
+        n = len(ld[1]) // 14
+        hit = 0
+        for i in range(n):
+            if struct.unpack_from('<H', ld[1], i * 14 + 12)[0] != 0xFFFF and hit < 12:
+                _set(ld, 14, i, '<H', 12, 0xFFFF)
+                hit += 1
+
+    @add('sidedef_sector_out_of_range')
+    def _(w):
+        sd = w.level_lump(LEVEL, 'SIDEDEFS')
+        for i in (1, 8, 33):
+            _set(sd, 30, i, '<H', 28, 0xFFF0)
+
+    @add('linedef_vertices_out_of_range')
+    def _(w):
+        ld = w.level_lump(LEVEL, 'LINEDEFS')
+        _set(ld, 14, 6, '<H', 0, 0xFFF0)
+        _set(ld, 14, 12, '<H', 2, 0xFFF0)
+
+    @add('things_of_unknown_type_and_outside_the_map')
+    def _(w):
+        th = w.level_lump(LEVEL, 'THINGS')
+        _set(th, 10, 2, '<H', 6, 31999)
+        _set(th, 10, 3, '<h', 0, 32000)
+        _set(th, 10, 3, '<h', 2, -32000)
+
+    @add('no_player_start')
+    def _(w):
+        th = w.level_lump(LEVEL, 'THINGS')
+        for i in range(len(th[1]) // 10):
+            if struct.unpack_from('<H', th[1], i * 10 + 6)[0] == 1:
+                _set(th, 10, i, '<H', 6, 31998)
+
+    @add('sector_heights_inverted_and_extreme')
+    def _(w):
+        sec = w.level_lump(LEVEL, 'SECTORS')
+        _set(sec, 26, 0, '<h', 0, 32767)
+        _set(sec, 26, 1, '<h', 2, -32768)
+        _set(sec, 26, 2, '<H', 20, 65535)               # light level
+        _set(sec, 26, 3, '<H', 22, 65535)               # sector type
+
+    @add('unknown_flat_and_wall_names')
+    def _(w):
+        sec = w.level_lump(LEVEL, 'SECTORS')
+        sec[1][4:12] = b'NOFLAT__'
+        sec[1][26 + 12:26 + 20] = b'NOCEIL__'
+        sd = w.level_lump(LEVEL, 'SIDEDEFS')
+        sd[1][4:12] = b'NOUPPER_'
+        sd[1][30 + 20:30 + 28] = b'NOMIDDLE'
+
+    @add('invalid_name_bytes_in_the_level')
+    def _(w):
+        sec = w.level_lump(LEVEL, 'SECTORS')
+        sec[1][4:12] = b'\x01\x02bad\xff\x00\x00'
+
+    # ---- textures ------------------------------------------------------------------------------------------------------
+    @add('pnames_names_a_missing_patch')
+    def _(w):
+        pn = w.named('PNAMES')
+        pn[1][4:12] = b'NOPATCH_'
+
+    @add('texture1_patch_index_out_of_range')
+    def _(w):
+        tx = w.named('TEXTURE1')
+        n, = struct.unpack_from('<i', tx[1], 0)
+        off, = struct.unpack_from('<i', tx[1], 4 + 4 * (n // 2))
+        struct.pack_into('<h', tx[1], off + 22 + 4, 0x7FF0)   # first patch reference: patch number
+
+    @add('texture1_offset_beyond_the_lump')
+    def _(w):
+        tx = w.named('TEXTURE1')
+        struct.pack_into('<i', tx[1], 4, 0x7FFFFFF0)
+
+    @add('texture1_truncated')
+    def _(w):
+        tx = w.named('TEXTURE1')
+        del tx[1][len(tx[1]) // 2:]
+
+    @add('patch_column_offset_beyond_the_lump')
+    def _(w):
+        pn = w.named('PNAMES')
+        first = bytes(pn[1][4:12]).rstrip(b'\0').decode()
+        patch = w.named(first)
+        struct.pack_into('<i', patch[1], 8, 0x7FFFFFF0)
+
+    @add('patch_truncated_mid_column')
+    def _(w):
+        pn = w.named('PNAMES')
+        first = bytes(pn[1][4:12]).rstrip(b'\0').decode()
+        patch = w.named(first)
+        del patch[1][-7:]
+
+    @add('patch_of_huge_size')
+    def _(w):
+        pn = w.named('PNAMES')
+        first = bytes(pn[1][4:12]).rstrip(b'\0').decode()
+        struct.pack_into('<HH', w.named(first)[1], 0, 20000, 20000)
+
+    @add('playpal_truncated')
+    def _(w):
+        del w.named('PLAYPAL')[1][-5:]
+
+    @add('colormap_short')
+    def _(w):
+        del w.named('COLORMAP')[1][256 * 10:]
+
+    # ---- the container ---------------------------------------------------------------------------------------------------
+    out.append(('lump_beyond_the_end_of_the_file', lambda w: dict(dir_patch={5: lambda pos, size: (0x7FFFFF00, size)})))
+    out.append(('negative_lump_size', lambda w: dict(dir_patch={7: lambda pos, size: (pos, -16)})))
+    out.append(('directory_beyond_the_end_of_the_file', lambda w: dict(header_patch=lambda b: struct.pack_into('<i', b, 8, 0x7FFFFFF0))))
+    out.append(('negative_lump_count', lambda w: dict(header_patch=lambda b: struct.pack_into('<i', b, 4, -5))))
+    out.append(('huge_lump_count', lambda w: dict(header_patch=lambda b: struct.pack_into('<i', b, 4, 0x7FFFFFF0))))
+    out.append(('bad_magic', lambda w: dict(header_patch=lambda b: struct.pack_into('<4s', b, 0, b'JWAD'))))
+    # ---- seeded random damage to the level's own lumps ----------------------------------------------------------------
+    for seed in range(24):
+        def noise(w, seed=seed):
+            rng = np.random.RandomState(1000 + seed)
+            for _ in range(int(rng.randint(1, 9))):
+                # (numeric fields only: a damaged NAME is a CorruptWad in the reference as well -- name.rs:41-75 -- and
+                # would end most mutants before the walker sees them; invalid_name_bytes_in_the_level covers that)
+                lump = ['THINGS', 'LINEDEFS', 'VERTEXES', 'SEGS', 'SSECTORS', 'NODES', 'SIDEDEFS', 'SECTORS'][int(rng.randint(8))]
+                data = w.level_lump(LEVEL, lump)[1]
+                rec = RECORD[lump]
+                index = int(rng.randint(len(data) // rec))
+                field = {'SIDEDEFS': [0, 2, 28], 'SECTORS': [0, 2, 20, 22, 24]}.get(lump, list(range(0, rec, 2)))
+                struct.pack_into('<H', data, index * rec + field[int(rng.randint(len(field)))], int(rng.randint(65536)))
+        out.append(('noise_%02d' % seed, noise))
+    for seed in range(8):   # heavy damage: dozens of fields at once
+        def heavy(w, seed=seed):
+            rng = np.random.RandomState(5000 + 2 * seed)
+            for _ in range(int(rng.randint(10, 60))):
+                lump = ['THINGS', 'LINEDEFS', 'VERTEXES', 'SEGS', 'SSECTORS', 'NODES', 'SIDEDEFS', 'SECTORS'][int(rng.randint(8))]
+                data = w.level_lump(LEVEL, lump)[1]
+                rec = RECORD[lump]
+                index = int(rng.randint(len(data) // rec))
+                field = {'SIDEDEFS': [0, 2, 28], 'SECTORS': [0, 2, 20, 22, 24]}.get(lump, list(range(0, rec, 2)))
+                struct.pack_into('<H', data, index * rec + field[int(rng.randint(len(field)))], int(rng.randint(65536)))
+        out.append(('heavy_noise_%02d' % seed, heavy))
+    for seed in range(12):  # single bytes of the texture lumps: PNAMES, TEXTURE1 and the patches
+        def texnoise(w, seed=seed):
+            rng = np.random.RandomState(7000 + seed)
+            start = [i for i, (n, _) in enumerate(w.lumps) if n.rstrip(b'\0') == b'P_START'][0]
+            end = [i for i, (n, _) in enumerate(w.lumps) if n.rstrip(b'\0') == b'P_END'][0]
+            pool = [w.named('PNAMES'), w.named('TEXTURE1')] + [w.lumps[i] for i in range(start + 1, end)]
+            for _ in range(int(rng.randint(1, 6))):
+                data = pool[int(rng.randint(len(pool)))][1]
+                if len(data) >= 4:
+                    data[int(rng.randint(len(data) - 1))] = int(rng.randint(256))
+        out.append(('texture_noise_%02d' % seed, texnoise))
+    return out
+
+
+MUTATIONS = mutations()
+# the reference warns and skips here: a level must come out (not merely "the same outcome as the oracle")
+MUST_BUILD = {'node_child_subsector_out_of_range', 'node_child_node_out_of_range', 'ssector_segs_out_of_range',
+              'seg_linedef_out_of_range', 'seg_vertices_out_of_range', 'linedef_sidedefs_missing',
+              'two_sided_lines_lose_their_back_side', 'sidedef_sector_out_of_range', 'linedef_vertices_out_of_range',
+              'things_of_unknown_type_and_outside_the_map', 'no_player_start', 'sector_heights_inverted_and_extreme',
+              'unknown_flat_and_wall_names', 'pnames_names_a_missing_patch', 'texture1_patch_index_out_of_range',
+              'patch_column_offset_beyond_the_lump', 'patch_truncated_mid_column', 'patch_of_huge_size',
+              'lump_beyond_the_end_of_the_file', 'negative_lump_size'}
+
+
+def _oracle_outcome(path):
+    try:
+        lv = wad_oracle.build_level(path, META_PATH, LEVEL)
+    except wad_oracle.WadError as e:
+        return ('error', str(e))
+    c = 0
+    for name in ('static_vertices', 'static_indices', 'sky_vertices', 'sky_indices', 'decor_vertices', 'decor_indices', 'draws',
+                 'flat_atlas', 'wall_atlas', 'decor_atlas', 'sky_texture', 'colormap'):
+        c = zlib.crc32(np.ascontiguousarray(getattr(lv, name)).tobytes(), c)
+    c = zlib.crc32(np.asarray(lv.lights.fill_buffer_at(1.25), np.uint8).tobytes(), c)
+    return ('level', '%08x' % c)
+
+
+def _driver_outcome(driver, path):
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0:halt_on_error=1', UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1')
+    p = subprocess.run([driver, path, META_PATH, str(LEVEL), str(LEVEL)], capture_output=True, text=True, timeout=120, env=env)
+    report = p.stderr if ('Sanitizer' in p.stderr or 'runtime error' in p.stderr) else ''
+    assert p.returncode == 0 and not report, 'sanitized host library: exit %d\n%s' % (p.returncode, p.stderr[-3000:])
+    lines = p.stdout.split('\n')
+    open_status = int(lines[0].split()[1])
+    if open_status != 0:
+        return ('error', open_status)
+    for ln in lines:
+        if ln.startswith('LEVEL %d ' % LEVEL):
+            f = ln.split()
+            return ('error', int(f[2])) if int(f[2]) != 0 else ('level', f[-1])
+    raise AssertionError(p.stdout)
+
+
+def test_clean_iwad_under_the_sanitizers(driver, wad_path, oracle_levels):
+    """all nine levels of the unmodified IWAD: no report, and the digest equals the oracle's"""
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1')
+    p = subprocess.run([driver, wad_path, META_PATH, '0', '8'], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and 'Sanitizer' not in p.stderr and 'runtime error' not in p.stderr, p.stderr[-3000:]
+    assert p.stdout.count('LEVEL') == 10
+    kind, digest = _oracle_outcome(wad_path)
+    assert kind == 'level' and ('LEVEL %d 0 ' % LEVEL) in p.stdout and digest in p.stdout
+
+
+@pytest.mark.parametrize('name', [m[0] for m in MUTATIONS])
+def test_malformed_iwad(driver, wad_path, tmp_path, name):
+    w = WadFile(wad_path)
+    kw = dict(MUTATIONS)[name](w) or {}
+    path = str(tmp_path / 'mutant.wad')
+    w.write(path, **kw)
+    got = _driver_outcome(driver, path)
+    want = _oracle_outcome(path)
+    assert got[0] == want[0], (name, got, want)
+    assert got[0] == 'level' or name not in MUST_BUILD, (name, got, want)
+    if got[0] == 'level':
+        assert got[1] == want[1], (name, got, want)   # warn-and-skip: the same level comes out
+    else:
+        assert got[1] in (-5, -6, -7), (name, got, want)   # RDOOM_IO / RDOOM_CORRUPT_WAD / RDOOM_CORRUPT_META
