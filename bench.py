@@ -64,6 +64,8 @@ def parse_args(argv=None):
     ap.add_argument('--streams', type=int, default=1,
                     help='experiment: S sub-batches on S HIP streams (per-kernel times then overlap; default 1)')
     ap.add_argument('--cpu-sample', type=int, default=512, help='poses rendered by the CPU oracle (0 = skip)')
+    ap.add_argument('--debug', action='append', default=[], metavar='NAME=VALUE',
+                    help='experiment: rdoom_debug_set hook (an equivalent path: same image), e.g. frag_bw=2; repeatable')
     ap.add_argument('--dry-run', action='store_true',
                     help='everything but the device work (rank launch, pose partition, barrier): for hosts without a GPU; prints no value')
     return ap.parse_args(argv)
@@ -97,6 +99,20 @@ def workload_key(args, levels):
     return '%s|levels=%s|%dx%d|poses=%d|tv=%d' % ('big' if args.big else (os.path.basename(args.iwad) if args.iwad else 'synth'),
                                                    ','.join(map(str, levels)), args.width, args.height, args.poses,
                                                    int(args.time_varying)) + ('|streams=%d' % args.streams if args.streams > 1 else '')
+
+
+def metric_label(args, levels):
+    """BASELINE.json's metric for the default workload; for the others the same quantity with the workload named
+    (`config.workload` stays the authoritative description)"""
+    if args.iwad:
+        what = '%s level(s) %s' % (os.path.basename(args.iwad), ','.join(map(str, levels)))
+    elif args.big:
+        what = '10x-E1M1'
+    elif len(levels) == 1:
+        what = 'E1M%d' % (levels[0] + 1)
+    else:
+        what = 'E1M%d-E1M%d' % (levels[0] + 1, levels[-1] + 1) if levels == list(range(levels[0], levels[-1] + 1)) else 'E1M' + ','.join(str(i + 1) for i in levels)
+    return 'Mpixels/s, %s %dx%d pose batch%s' % (what, args.width, args.height, ', time-varying' if args.time_varying else '')
 
 
 def spawn_ranks(args):
@@ -168,6 +184,9 @@ def main():
     else:
         dist = None
     rd.set_device(device_index)
+    for item in args.debug:
+        name, _, value = item.partition('=')
+        rd.debug_set(name, int(value or 1))
 
     iwad = args.iwad or (synthetic.ensure_big_wad() if args.big else synthetic.ensure_wad())
     meta = args.metadata or synthetic.META_PATH
@@ -274,10 +293,24 @@ def main():
             tc = time.perf_counter()
             ro.render_batch(sample, li, args.width, args.height, threads=cores)
             tc = time.perf_counter() - tc
+            # the same scalar loop on ONE thread (a few poses: about a second per megapixel), and the CPU-only geometry
+            # build of BASELINE config 1 timed per phase on one thread (tools/dump_geometry.py: t_load = rows a1-a7,
+            # t_walk = rows a9-a15 of SURVEY 8(a); medians of 9 runs, no GPU involved)
+            n1 = min(n, max(1, int(round(4.0e6 / frame_px))))
+            t1 = time.perf_counter()
+            ro.render_batch(sample[:n1], li[:n1], args.width, args.height, threads=1)
+            t1 = time.perf_counter() - t1
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import dump_geometry
+            host = dump_geometry.host_timings(iwad, meta, levels[0])
             cpu = {'value': round(n * frame_px / tc / 1e6, 3), 'unit': 'Mpixels/s',
                    'cores': min(cores, n), 'kind': 'port',
-                   'sample': '%d poses of the same sweep at %dx%d, oracle/raster_oracle.c, %.1f s; level build '
-                             '(C++ walk + device tessellation kernels, first use) %.1f ms' % (n, args.width, args.height, tc, t_build * 1e3)}
+                   'sample': '%d poses of the same sweep at %dx%d, oracle/raster_oracle.c, %.1f s on %d threads; single thread: '
+                             '%d poses in %.1f s; geometry build: CPU-only C++ path (use_gpu_tessellation = 0), one thread, '
+                             'median of %d runs' % (n, args.width, args.height, tc, min(cores, n), n1, t1, host['repeat']),
+                   't_raster_1': {'value': round(n1 * frame_px / t1 / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1, 'poses': n1},
+                   't_load_ms': host['t_load_ms'], 't_walk_ms': host['t_walk_ms'], 'geometry_phases_ms': host['phases_ms'],
+                   'geometry_first_run_ms': host['first_run_ms']}
         if args.iwad:
             what = 'level(s) %s of %s' % (','.join(map(str, levels)), os.path.basename(iwad))
         elif args.big:
@@ -287,7 +320,7 @@ def main():
         else:
             what = 'E1M%s (synthetic IWAD, tools/mkwad.py), one batch per level' % ','.join(str(i + 1) for i in levels)
         out = {
-            'metric': 'Mpixels/s, E1M1 1920x1080 pose batch', 'value': round(total_px / elapsed / 1e6, 1),
+            'metric': metric_label(args, levels), 'value': round(total_px / elapsed / 1e6, 1),
             'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f32+u8', 'data': 'synthetic',
@@ -297,11 +330,12 @@ def main():
                                       'per GPU' if args.scaling == 'weak' else 'in total, cut into contiguous ranges',
                                       ', pose i at time i/35 s with its own light table' if args.time_varying else ''),
                        'levels': levels, 'poses_per_gpu': n_mine, 'width': args.width, 'height': args.height,
+                       # (counts of the LAST render of each batch x renders: every step re-renders the same poses)
                        'visible_triangles_per_pose': round(acc.get('visible_triangles', 0) / max(1, args.steps * n_mine * len(levels)), 1),
                        'alpha_leak_fixup_pixels_per_step': acc.get('fixup_pixels', 0) // max(1, args.steps),
                        'kernels_ms': {k[:-3]: round(acc[k] / args.steps, 3) for k in ('setup_ms', 'raster_ms', 'fragment_ms')},
                        'parallelism': 'pose-sharded x%d, no collective' % world,
-                       'streams': args.streams,
+                       'streams': args.streams, **({'debug': args.debug} if args.debug else {}),
                        'workload_key': workload_key(args, levels), 'kernel_sources': kernel_source_digest()},
             'roofline': {'bound': 'hbm', 'kernel': 'fragment_kernel', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),

@@ -128,6 +128,18 @@ typedef struct rdoom_timings {
   uint64_t fixup_pixels; /* pixels re-resolved by the alpha-leak fixup kernel (normally a handful) */
 } rdoom_timings;
 
+/* Host-side times of the load and build phases, the ones the reference logs with one-shot Instants (wad/src/tex.rs:67-88,
+ * 371-408, 479-495; game/src/level.rs:333, 384-396).  Single thread, wall clock (std::chrono::steady_clock).
+ * rdoom_wad_timings fills open_ms + textures_ms (the others are 0); rdoom_built_timings fills the other four. */
+typedef struct rdoom_host_timings {
+  float open_ms;        /* Archive::open: header, directory, metadata (archive.rs:36-106, meta.rs:143-154) */
+  float textures_ms;    /* TextureDirectory::from_archive: PLAYPAL, COLORMAP, patches, TEXTURE1/2, flats, sprites (tex.rs:53-107) */
+  float level_lumps_ms; /* Level::from_archive: the eight lumps of the level (level.rs:34-81) */
+  float atlases_ms;     /* build_flat_atlas + build_texture_atlas (walls, decor) + sky (game_shaders.rs:175-387) */
+  float analysis_ms;    /* LevelAnalysis::new (visitor.rs:323-444) */
+  float walk_ms;        /* LevelWalker::walk driving the Builder, then the index lists (level.rs:330-496) */
+} rdoom_host_timings;
+
 /* counters logged by the reference at level build (game/src/level.rs:384-422) */
 typedef struct rdoom_counters {
   uint32_t num_wall_quads, num_floor_polys, num_ceil_polys, num_sky_wall_quads, num_sky_floor_polys,
@@ -212,6 +224,7 @@ rdoom_status rdoom_debug_set(const char *name, int32_t value);
 /* Archive::open (wad/src/archive.rs:36-60) + TextureDirectory::from_archive (wad/src/tex.rs:53-107) */
 rdoom_status rdoom_wad_open(const char *wad_path, const char *metadata_path, rdoom_wad **out_wad);
 void rdoom_wad_close(rdoom_wad *wad);
+rdoom_status rdoom_wad_timings(const rdoom_wad *wad, rdoom_host_timings *out);    /* how long rdoom_wad_open's phases took */
 rdoom_status rdoom_wad_num_levels(const rdoom_wad *wad, uint32_t *out);           /* Archive::num_levels */
 rdoom_status rdoom_wad_level_name(const rdoom_wad *wad, uint32_t index, char out_name[9]); /* WadSystem::level_name */
 /* WadName::from_bytes (wad/src/name.rs:41-75); out = 8 bytes */
@@ -300,6 +313,7 @@ void rdoom_built_destroy(rdoom_built *built);
 /* borrowed pointers into `built`, valid until rdoom_built_destroy */
 rdoom_status rdoom_built_desc(const rdoom_built *built, rdoom_level_desc *out_desc);
 rdoom_status rdoom_built_counters(const rdoom_built *built, rdoom_counters *out);
+rdoom_status rdoom_built_timings(const rdoom_built *built, rdoom_host_timings *out); /* how long the build's phases took */
 /* Lights::fill_buffer_at (game/src/lights.rs:26-30) */
 rdoom_status rdoom_built_lights_at(const rdoom_built *built, float time, uint8_t out_lights[256]);
 /* Builder::visit_marker start pose (game/src/level.rs:757-762) */

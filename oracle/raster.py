@@ -46,6 +46,7 @@ def _load():
         _lib.oracle_render_objects.restype = ctypes.c_int
         _lib.oracle_render_batch.restype = ctypes.c_int
         _lib.oracle_render_varyings.restype = ctypes.c_int
+        _lib.oracle_shade_varyings.restype = ctypes.c_int
     return _lib
 
 
@@ -117,6 +118,23 @@ class RasterOracle:
         if rc:
             raise MemoryError('oracle_render_varyings failed')
         return fb, prim, var
+
+    def shade_varyings(self, time, lights, prim, var):
+        """The oracle's binary32 fragment stage (F2..F6) on varyings from outside: prim (h, w) u32 winners (NO_PRIM: none),
+        var (h, w, 3) float32 = (v_tile_uv, v_dist), or the folded sky uv.  Returns (h, w) u16: palette index, 0x100 =
+        discarded by the alpha test, 0xFFFF = no primitive."""
+        lib = _load()
+        prim = np.ascontiguousarray(prim, np.uint32)
+        var = np.ascontiguousarray(var, np.float32)
+        h, w = prim.shape
+        li = np.ascontiguousarray(lights, np.uint8).reshape(256)
+        out = np.zeros((h, w), np.uint16)
+        rc = lib.oracle_shade_varyings(ctypes.byref(self.level), ctypes.c_float(float(time)), li.ctypes.data_as(ctypes.c_void_p),
+                                       int(w), int(h), prim.ctypes.data_as(ctypes.c_void_p), var.ctypes.data_as(ctypes.c_void_p),
+                                       out.ctypes.data_as(ctypes.c_void_p))
+        if rc:
+            raise MemoryError('oracle_shade_varyings failed')
+        return out
 
     def render_batch(self, poses, lights, width, height, kinds=ALL_KINDS, threads=1):
         """poses: (n,33) float32 [modelview16, projection16, time]; lights: (n,256) u8."""

@@ -191,6 +191,7 @@ static int setup_tri(const float clip[3][4], const float u[3], const float v[3],
 static float plane(const float *p, float px, float py) { return fmaf(p[0], px, fmaf(p[1], py, p[2])); }
 
 /* static.frag:19-20 texel fetch.  Returns the raw texel (u16; flats are promoted, never transparent). */
+static uint32_t texel_at(const OracleLevel *L, const Setup *s, float tu, float tv);
 static uint32_t fetch_texel(const OracleLevel *L, const Setup *s, float px, float py, float *dist, float *tuv) {
   float rw = plane(s->wp, px, py);
   float w = 1.0f / rw;
@@ -198,6 +199,11 @@ static uint32_t fetch_texel(const OracleLevel *L, const Setup *s, float px, floa
   float tv = plane(s->vp, px, py) * w;
   *dist = w;
   if (tuv) tuv[0] = tu, tuv[1] = tv;
+  return texel_at(L, s, tu, tv);
+}
+
+/* static.frag:19-20 / sprite.frag:19 on given v_tile_uv: F2 (mod + atlas offset), F3 (REPEAT + NEAREST) */
+static uint32_t texel_at(const OracleLevel *L, const Setup *s, float tu, float tv) {
   float uvx = glsl_mod(tu, s->size_x) + s->atlas_u;
   float uvy = glsl_mod(tv, s->size_y) + s->atlas_v;
   int ix = (int)floorf(uvx), iy = (int)floorf(uvy);
@@ -257,6 +263,7 @@ static void xform_decor(const float *m, const float *p, const SpriteVertex *v, f
     clip[r] = fmaf(p[12 + r], eye[3], fmaf(p[8 + r], eye[2], fmaf(p[4 + r], eye[1], p[0 + r] * eye[0])));
 }
 
+static uint8_t sky_texel_colour(const OracleLevel *L, float uvx, float uvy);
 /* sky.frag:12-26.  v_p = clip position interpolated (x/w, y/w are NDC), v_r flat per pose. */
 static uint8_t shade_sky(const OracleLevel *L, float px, float py, int width, int height, const float *vr) {
   float ndc_x = px / (0.5f * (float)width) - 1.0f;
@@ -273,7 +280,11 @@ static uint8_t shade_sky(const OracleLevel *L, float px, float py, int width, in
   } else if (uvy >= 1.0f) {
     uvy = 1.0f - uvy;
   }
-  /* REPEAT + NEAREST on normalised coordinates */
+  return sky_texel_colour(L, uvx, uvy);
+}
+
+/* sky.frag:24-25 on the folded uv: REPEAT + NEAREST on normalised coordinates, palette row 0 */
+static uint8_t sky_texel_colour(const OracleLevel *L, float uvx, float uvy) {
   float fx = uvx - floorf(uvx), fy = uvy - floorf(uvy);
   int ix = (int)floorf(fx * (float)L->sky_w), iy = (int)floorf(fy * (float)L->sky_h);
   if (ix >= (int)L->sky_w) ix = (int)L->sky_w - 1;
@@ -457,4 +468,66 @@ int oracle_render_varyings(const OracleLevel *L, const float *modelview, const f
   free(depth);
   free(prim);
   return rc;
+}
+
+/* Zero-tolerance pin of the fragment stage (tests/gl_census.py: fragment_exact): THIS file's binary32 fragment code --
+ * F2..F6 of DESIGN.md, i.e. static.frag:18-28, sprite.frag:15-27, sky.frag:24-25 -- applied to varyings that come from
+ * OUTSIDE (the ones the reference's own shaders interpolated under SwiftShader, read back by an auxiliary pass) for the
+ * primitive that won there.  in_prim: primitive id per pixel (NO_PRIM: nothing drawn); in_var: per pixel
+ * (v_tile_uv.x, v_tile_uv.y, v_dist), or the folded (uv.x, uv.y, -1) of sky.frag:23.  out: palette index 0..255,
+ * 0x100 = the fragment would have been discarded (transparent texel), 0xFFFF = no primitive. */
+int oracle_shade_varyings(const OracleLevel *L, float time, const uint8_t *lights, int width, int height,
+                          const uint32_t *in_prim, const float *in_var, uint16_t *out) {
+  size_t npx = (size_t)width * (size_t)height;
+  uint32_t total = 0;
+  for (uint32_t d = 0; d < L->n_draws; d++) total += L->draws[d].index_count / 3;
+  uint32_t *draw_of = (uint32_t *)malloc(((size_t)total + 1) * sizeof(uint32_t));
+  if (!draw_of) return -1;
+  uint32_t *first_of = (uint32_t *)malloc(((size_t)L->n_draws + 1) * sizeof(uint32_t));
+  if (!first_of) {
+    free(draw_of);
+    return -1;
+  }
+  uint32_t at = 0;
+  for (uint32_t d = 0; d < L->n_draws; d++) {
+    first_of[d] = at;
+    for (uint32_t t = 0; t < L->draws[d].index_count / 3; t++) draw_of[at++] = d;
+  }
+  for (size_t o = 0; o < npx; o++) {
+    uint32_t pid = in_prim[o];
+    if (pid == NO_PRIM || pid >= total) {
+      out[o] = 0xFFFFu;
+      continue;
+    }
+    const Draw *dr = &L->draws[draw_of[pid]];
+    uint32_t t = pid - first_of[draw_of[pid]];
+    const float *var = in_var + 3 * o;
+    if (dr->kind == KIND_SKY) {
+      out[o] = sky_texel_colour(L, var[0], var[1]);
+      continue;
+    }
+    Setup s;
+    memset(&s, 0, sizeof s);
+    s.kind = dr->kind;
+    if (dr->kind == KIND_DECOR) {
+      const SpriteVertex *pv = &L->decor_verts[L->decor_indices[dr->first_index + 3 * t + 2]];
+      sprite_atlas_uv_at(pv, time, (float)L->decor_w, &s.atlas_u, &s.atlas_v);
+      s.size_x = pv->a_tile_size[0], s.size_y = pv->a_tile_size[1];
+      s.light = (float)lights[pv->a_light] / 255.0f;
+    } else {
+      const StaticVertex *pv = &L->static_verts[L->static_indices[dr->first_index + 3 * t + 2]];
+      atlas_uv_at(pv, time, dr->kind == KIND_FLAT ? (float)L->flat_w : (float)L->wall_w, &s.atlas_u, &s.atlas_v);
+      s.size_x = pv->a_tile_size[0], s.size_y = pv->a_tile_size[1];
+      s.light = (float)lights[pv->a_light] / 255.0f;
+    }
+    uint32_t texel = texel_at(L, &s, var[0], var[1]);
+    if (dr->kind != KIND_FLAT && (texel & 0x8000u)) {
+      out[o] = 0x100u;
+      continue;
+    }
+    out[o] = dr->kind == KIND_DECOR ? shade_decor(L, texel & 0xFFu, s.light, var[2]) : shade(L, texel & 0xFFu, s.light, var[2]);
+  }
+  free(first_of);
+  free(draw_of);
+  return 0;
 }

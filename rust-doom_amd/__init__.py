@@ -61,6 +61,10 @@ class Timings(ctypes.Structure):
                 ('fixup_pixels', ctypes.c_uint64)]
 
 
+class HostTimings(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ('open_ms', 'textures_ms', 'level_lumps_ms', 'atlases_ms', 'analysis_ms', 'walk_ms')]
+
+
 class Counters(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in
                 ('num_wall_quads', 'num_floor_polys', 'num_ceil_polys', 'num_sky_wall_quads', 'num_sky_floor_polys',
@@ -76,7 +80,8 @@ API_SYMBOLS = [
     'rdoom_wad_open', 'rdoom_wad_close', 'rdoom_wad_num_levels', 'rdoom_wad_level_name',
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
     'rdoom_built_counters', 'rdoom_built_lights_at', 'rdoom_built_start', 'rdoom_built_floor_centroids',
-    'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_debug_set', 'rdoom_wad_walk', 'rdoom_wad_build_level_chained', 'rdoom_batch_render_objects', 'rdoom_level_num_objects', 'rdoom_batch_enable_primitive_ids']
+    'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_debug_set', 'rdoom_wad_walk', 'rdoom_wad_build_level_chained', 'rdoom_batch_render_objects', 'rdoom_level_num_objects', 'rdoom_batch_enable_primitive_ids',
+    'rdoom_wad_timings', 'rdoom_built_timings']
 
 _lib = None
 
@@ -283,6 +288,12 @@ class Wad:
     def __del__(self):
         _close_quietly(self)
 
+    def timings(self):
+        """open_ms, textures_ms of rdoom_wad_open (single thread, steady clock inside the library)"""
+        t = HostTimings()
+        _check(lib().rdoom_wad_timings(self._h, ctypes.byref(t)))
+        return {n: getattr(t, n) for n, _ in HostTimings._fields_}
+
     def num_levels(self):
         n = ctypes.c_uint32()
         _check(lib().rdoom_wad_num_levels(self._h, ctypes.byref(n)))
@@ -357,6 +368,12 @@ class BuiltLevel:
         c = Counters()
         _check(lib().rdoom_built_counters(self._h, ctypes.byref(c)))
         return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def timings(self):
+        """level_lumps_ms, atlases_ms, analysis_ms, walk_ms of this build"""
+        t = HostTimings()
+        _check(lib().rdoom_built_timings(self._h, ctypes.byref(t)))
+        return {n: getattr(t, n) for n, _ in HostTimings._fields_}
 
     def lights_at(self, time):
         out = np.zeros(256, np.uint8)

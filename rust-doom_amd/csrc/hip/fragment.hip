@@ -45,6 +45,9 @@ namespace {
 #ifdef RDOOM_FRAG_STATS  // census build (tools/variant.sh fstats fragment -DRDOOM_FRAG_STATS): where do the runs go?
 __device__ unsigned long long g_frag_stats[16];
 #endif
+#ifndef RDOOM_FRAG_MAGIC
+#define RDOOM_FRAG_MAGIC 0  // texel addresses through the round-down magic-number floor (0: four v_cvt_flr_i32_f32 per pixel pair)
+#endif
 #ifndef RDOOM_FRAG_CHUNK
 #define RDOOM_FRAG_CHUNK 16
 #endif
@@ -112,24 +115,36 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
   return cmap[rowc * 256 + (int)(texel & 0xFFu)];
 }
 
+// What only the kernel's rare paths read (the general per-pixel body, sky runs, the alpha-leak queue), in device memory
+// rather than in the kernel arguments: kernel arguments are scalar registers for the whole kernel, and the hot loop has
+// none to spare (106 of 106 in use).  One per batch, written once (launch_fragment).
+struct FragConst {
+  DeviceLevelView lv;
+  uint32_t *fix_count;
+  uint2 *fix_list;
+  const float *ndc_tab;
+  uint32_t fix_cap, div_m, div_sh, pad;
+};
+
 template <int NQ, int DBG, bool VIS16>  // NQ: adjacent quads per lane (1 or 2; the frame width is a multiple of 4 NQ);
                                         // DBG: timing experiments only; VIS16: 16-bit visibility words (0xFFFF = none)
-__global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
+__global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment_kernel(const FragConst *__restrict__ fc,
+                                                       const uint16_t *__restrict__ texels, const uint8_t *__restrict__ colormap,
+                                                       const TriRec *__restrict__ recs,
                                                        uint32_t cap, const PoseConst *__restrict__ poses,
                                                        const uint32_t *__restrict__ vis, uint32_t n_poses,
                                                        uint32_t chunks_per_pose, uint32_t chunk_iters,
-                                                       uint32_t quads_per_pose,
-                                                       uint32_t quads_per_row, uint32_t div_m, uint32_t div_sh,
+                                                       uint32_t quads_per_pose, uint32_t quads_per_row,
                                                        uint32_t wblocks_per_row, uint32_t wblocks_per_pose, uint32_t bw_log2,
-                                                       int width, int height, const float *__restrict__ ndc_tab,
-                                                       uint8_t *__restrict__ fb, uint32_t *__restrict__ fix_count,
-                                                       uint2 *__restrict__ fix_list, uint32_t fix_cap,
-                                                       uint32_t debug_leak_mod) {
+                                                       int width, int height,
+                                                       uint8_t *__restrict__ fb,
+                                                       uint32_t debug_leak_mod, const uint32_t *__restrict__ qtab,
+                                                       uint32_t qtab_mode, uint32_t tiles_x, uint32_t n_tiles) {
   constexpr int NP = 2 * NQ, NPX = 4 * NQ;  // float2 pairs and pixels per lane
   __shared__ uint8_t cmap[32 * 256];
   __shared__ uint32_t wlist[FRAG_WAVES][FRAG_WLIST];
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(lv.colormap);
+    const uint4 *src = reinterpret_cast<const uint4 *>(colormap);
     uint4 *dst = reinterpret_cast<uint4 *>(cmap);
 #pragma unroll
     for (uint32_t k = threadIdx.x; k < 512u; k += 64u * FRAG_WAVES) dst[k] = src[k];
@@ -154,6 +169,8 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
   auto shade_listed = [&](uint32_t first, uint32_t count) {
     const uint32_t j = lane >> 2, k = lane & 3u;
     if (j < count) {
+      const DeviceLevelView &lv = fc->lv;  // (read here, on the rare path, not held in registers through the hot loop)
+      const uint32_t div_m = fc->div_m, div_sh = fc->div_sh;
       const uint32_t qi = mylist[first + j];
       const uint32_t row = fast_div(qi, div_m, div_sh), qx = qi - row * quads_per_row;
       const uint32_t id = VIS16 ? (uint32_t)pvis16[(size_t)qi * 4u + k] : pvis32[(size_t)qi * 4u + k];
@@ -174,8 +191,8 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         // is exercised on ordinary pixels too -- the output must not change
         const bool forced = debug_leak_mod != 0u && pix % debug_leak_mod == 0u;
         if ((c & 0x100u) || forced) {  // rare: alpha leak, queue the pixel for exact re-resolution
-          const uint32_t slot = atomicAdd(fix_count, 1u);
-          if (slot < fix_cap) fix_list[slot] = make_uint2(pose, pix);
+          const uint32_t slot = atomicAdd(fc->fix_count, 1u);
+          if (slot < fc->fix_cap) fc->fix_list[slot] = make_uint2(pose, pix);
         }
       }
       uint32_t v = (c & 0xFFu) << (8u * k);
@@ -207,9 +224,29 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
     // visibility words of my NPX pixels: all the same?  (compared as loaded, two 16-bit words at a time; a lane outside
     // the frame reads unit 0 and is treated as background -- no divergent branch, no boolean phi)
     const uint32_t q0l = valid ? q0 : 0u;
+    // The rasteriser's quadrant table: when it says that every pixel of the 32 x 32 quadrant(s) this block lies in shows
+    // ONE record, the block's visibility words are neither loaded nor compared (all scalar: the block origin is uniform).
+    // qtab_mode 1: the block is 32 pixels wide (inside one quadrant); 2: 64 pixels wide (two quadrants of one tile, side
+    // by side -- the right one may lie outside the frame, where the rasteriser writes nothing).
+    uint32_t tq = NONE;
+    if (qtab_mode != 0u) {
+      const uint32_t bx0 = (wbx << bw_log2) * (uint32_t)NPX, by0 = wby << (6u - bw_log2);
+      const uint32_t *e = qtab + ((size_t)pose * n_tiles + ((by0 >> 6) * tiles_x + (bx0 >> 6))) * 4u + ((by0 >> 5) & 1u) * 2u;
+      if (qtab_mode == 1u) {
+        tq = e[(bx0 >> 5) & 1u];
+      } else {
+        const uint2 two = *reinterpret_cast<const uint2 *>(e);
+        tq = (two.x == two.y || bx0 + 32u >= (uint32_t)width) ? two.x : NONE;
+      }
+    }
+    tq = (uint32_t)__builtin_amdgcn_readfirstlane((int)tq);
+    const bool table_one = (tq != NONE) & (debug_leak_mod == 0u);
     uint32_t id0;
     bool uniform;
-    if (VIS16) {
+    if (table_one) {
+      id0 = tq;
+      uniform = true;
+    } else if (VIS16) {
       if (NQ == 2) {
         const uint4 v = *reinterpret_cast<const uint4 *>(pvis_bytes + q0l * 8u);
         id0 = v.x & 0xFFFFu;
@@ -262,7 +299,13 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
       // F3 parameters: one u16 texel store, REPEAT = masks
       const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
       const uint32_t base2 = base * 2u;  // byte offsets < 2^27: one 32-bit VGPR offset from the uniform base pointer
-      const char *tb = reinterpret_cast<const char *>(lv.texels);
+      const char *tb = reinterpret_cast<const char *>(texels);
+#if RDOOM_FRAG_MAGIC
+      const uint32_t wm2 = wm << 1;
+      // the store's base: with a wave-uniform record the pointer arithmetic is scalar; per-lane records keep a 32-bit offset
+      const char *tb2 = ONE ? tb + base2 : tb;
+      const uint32_t lane_base2 = ONE ? 0u : base2;
+#endif
       // Certificate for integer (non-power-of-two) tile sizes, evaluated only in waves that hold such a record
       // (fastmath.hpp, mod_cert): with guard >= 2^-20 * max(|x|, y), guard <= r <= y - guard and |x| < 2^23 imply that
       // no integer lies between x * RN(1/y) and RN(x / y) and that y * floor is exact.  One guard per run and axis:
@@ -307,6 +350,27 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
           mod_ok = mod_ok & (p2x | ((rx.x >= lox) & (rx.x <= hix) & (rx.y >= lox) & (rx.y <= hix))) &
                    (p2y | ((ry.x >= loy) & (ry.x <= hiy) & (ry.y >= loy) & (ry.y <= hiy)));
         const f32x2 ux = rx + splat(atlas_u), uy = ry + splat(atlas_v);  // F3
+#if RDOOM_FRAG_MAGIC
+        // floor() of four coordinates with two packed instructions: for 0 <= x < 2^22, x + 2^23 rounded TOWARDS MINUS
+        // INFINITY is 2^23 + floor(x) exactly (the sum lies in [2^23, 2^24), where binary32 has unit spacing), i.e. the
+        // bits 0x4B000000 + floor(x); the REPEAT masks below strip the exponent.  The horizontal coordinate goes through
+        // fma(x, 2, 2^23): floor(2x) = 2 floor(x) + {0, 1}, and the mask (wm << 1) drops the odd bit -- the byte offset of
+        // the 16-bit texel without a shift.  The rounding mode is switched for exactly these two instructions (one asm
+        // statement: nothing can be scheduled in between).  Coordinates are >= 0 in every lane whose result is used
+        // (mod results lie in [0, size], atlas positions are >= 0); other lanes produce masked, in-range garbage as before.
+        f32x2 fxb, fyb;
+        asm volatile(
+            "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\t"
+            "v_pk_fma_f32 %0, %2, 2.0, %4 op_sel_hi:[1,0,1]\n\t"
+            "v_pk_add_f32 %1, %3, %4\n\t"
+            "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+            : "=&v"(fxb), "=v"(fyb)
+            : "v"(ux), "v"(uy), "s"(f32x2{0x1p23f, 0x1p23f}));
+        const uint32_t o0 = ((__float_as_uint(fyb.x) & hm) << (lw + 1u)) | (__float_as_uint(fxb.x) & wm2);
+        const uint32_t o1 = ((__float_as_uint(fyb.y) & hm) << (lw + 1u)) | (__float_as_uint(fxb.y) & wm2);
+        texel[2 * p] = (DBG & 2) ? (o0 & 255u) : *reinterpret_cast<const TexelWord *>(tb2 + (ONE ? o0 : o0 + lane_base2));
+        texel[2 * p + 1] = (DBG & 2) ? (o1 & 255u) : *reinterpret_cast<const TexelWord *>(tb2 + (ONE ? o1 : o1 + lane_base2));
+#else
         const uint32_t o0 = (((uint32_t)cvt_floor_i32(uy.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.x) & wm);
         const uint32_t o1 = (((uint32_t)cvt_floor_i32(uy.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.y) & wm);
         // (a 32-bit load at the texel's 2-byte-aligned address: bits 0..7 = palette index and bit 15 = transparent are
@@ -314,6 +378,7 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         // load would be zero-extended again wherever it is used in another basic block: eight more instructions per run)
         texel[2 * p] = (DBG & 2) ? (o0 & 255u) : *reinterpret_cast<const TexelWord *>(tb + (o0 * 2u + base2));
         texel[2 * p + 1] = (DBG & 2) ? (o1 & 255u) : *reinterpret_cast<const TexelWord *>(tb + (o1 * 2u + base2));
+#endif
       }
       // rw is monotone along the run: both ends inside the verified range of the exact reciprocal forms
       // (one unsigned compare per end: the bit patterns of [2^-100, 2^100] are the integers [0x0D800000, 0x71800000];
@@ -362,8 +427,10 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
       }
     };
     // wave-uniform record?  (the broadcast is an unconditional initialiser, see DESIGN 5 on v_readlane under branches)
-    const uint32_t id_one = (uint32_t)__builtin_amdgcn_readfirstlane((int)id0);
-    const bool wave_one = __all(uniform & valid & (id0 == id_one)) & (id_one != NONE_ID) & (debug_leak_mod == 0u);
+    // (with the table a lane outside the frame may ride along: it stores nothing, its texel offsets are masked into range)
+    const uint32_t id_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)id0);
+    const uint32_t id_one = table_one ? tq : id_first;
+    const bool wave_one = table_one | (__all(uniform & valid & (id0 == id_one)) & (id_one != NONE_ID) & (debug_leak_mod == 0u));
     bool took_one = false;
     if (wave_one) {
       const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[id_one].s);
@@ -386,6 +453,8 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         // a run of sky (sky.frag:12-26): the colour depends on the pixel and the pose only.  ndc_tab holds
         // p / (size / 2) - 1 for every column and row of the frame (computed once per batch with the same two
         // operations), the record carries v_r.y and 4 v_r.x / 3.14159265358; the row part is evaluated once per run.
+        const DeviceLevelView &lv = fc->lv;
+        const float *ndc_tab = fc->ndc_tab;
         const float ushift = __uint_as_float(r2.w), vr1 = __uint_as_float(r2.z), band = lv.sky_band;
         float uvy = (-ndc_tab[(uint32_t)width + row] + 1.0f) + vr1;
         if (uvy < 0.0f) {
@@ -542,12 +611,15 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
 
 }  // namespace
 
+size_t fragment_const_bytes() { return sizeof(FragConst); }
+
 rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                              const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,
                              int width, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
                              const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
                              bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
-                             uint2 *fix_list, uint32_t fix_cap) {
+                             uint2 *fix_list, uint32_t fix_cap, const uint32_t *qtab, void *d_frag_const,
+                             bool *frag_const_ready) {
   const uint32_t n = n_poses;
   const int W = width, H = height;
   const uint32_t qpr = (uint32_t)W / 4u, qpp = qpr * (uint32_t)H;
@@ -582,8 +654,18 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
     frag = nq == 2 ? (vis16 ? fragment_kernel<2, 2, true> : fragment_kernel<2, 2, false>)
                    : (vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>);
 #endif
-  hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(64 * FRAG_WAVES), 0, st, lv, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp,
-                     qpr, div_m, div_sh, wbpr, wbpp, bwl, W, H, ndc_tab, fb, fix_count, fix_list, fix_cap, debug_leak_mod);
+  // the quadrant table serves blocks that lie inside one 32 x 32 quadrant, or inside two side by side
+  const uint32_t block_px = bw * 4u * (uint32_t)nq;
+  const uint32_t qtab_mode = (!qtab || dbg.no_qtab || bh > 32u) ? 0u : (block_px == 32u ? 1u : (block_px == 64u ? 2u : 0u));
+  if (!*frag_const_ready) {  // constant for the life of the batch: written once
+    FragConst h{};
+    h.lv = lv, h.fix_count = fix_count, h.fix_list = fix_list, h.ndc_tab = ndc_tab, h.fix_cap = fix_cap, h.div_m = div_m, h.div_sh = div_sh;
+    HIP_TRY(hipMemcpy(d_frag_const, &h, sizeof h, hipMemcpyHostToDevice));
+    *frag_const_ready = true;
+  }
+  hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(64 * FRAG_WAVES), 0, st, static_cast<const FragConst *>(d_frag_const), lv.texels,
+                     lv.colormap, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp, qpr, wbpr, wbpp, bwl, W, H, fb, debug_leak_mod, qtab,
+                     qtab_mode, (uint32_t)tiles_x, (uint32_t)(tiles_x * tiles_y));
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, H, tiles_x, tiles_y,
                      tile_hdr, entries, entry_cap, overflow, fix_count, fix_list, fix_cap, vis, vis16 ? 1u : 0u, prim_out, fb,
                      fix_count + 1);

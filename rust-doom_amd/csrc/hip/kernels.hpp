@@ -30,13 +30,16 @@ bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint
 rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
-                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out);
+                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out,
+                           uint32_t *qtab);  // qtab (optional): per (pose, tile, quadrant) the record all its pixels show, or NONE
 // Kernels 3 + 4: fragment kernel -> palette indices, then the alpha-leak fixup (fragment.hip)
 rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                              const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,
                              int width, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
                              const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
                              bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
-                             uint2 *fix_list, uint32_t fix_cap);
+                             uint2 *fix_list, uint32_t fix_cap, const uint32_t *qtab, void *d_frag_const,
+                             bool *frag_const_ready);  // d_frag_const: fragment_const_bytes() of device memory owned by the batch
+size_t fragment_const_bytes();
 
 }  // namespace rdoom_dev

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
                                                              const uint32_t *__restrict__ overflow,
                                                              uint32_t *__restrict__ vis, uint32_t vis16,
                                                              uint32_t *__restrict__ prim_out, uint32_t no_cover,
+                                                             uint32_t *__restrict__ qtab,
                                                              unsigned long long *__restrict__ stats) {
   unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __shared__ uint32_t wq[RASTER_WAVES][64];
@@ -383,6 +384,9 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
           if ((__ballot(dnq_s <= df0) & touch_s & ~(1ull << s0)) == 0ull) {
             const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)myrec, (int)s0);
             if (STATS) st[0] += (unsigned long long)__popcll(touch_s), st[9]++;
+            // the quadrant table: "all 1024 pixels show record r0" -- the fragment kernel's waves then take the record
+            // by scalar loads without reading (or comparing) the visibility words of this quadrant
+            if (qtab && lane == 0) qtab[((size_t)pose * T + tile) * 4u + (uint32_t)q] = r0;
             if (bx < width) {
               const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
               const uint32_t p0 = prim_out ? (prec[r0].r.flags & 0xFFFFFFu) : 0u;
@@ -490,6 +494,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       }
     }
     // ---- this quadrant's visibility words ------------------------------------------------------------------------
+    if (qtab && lane == 0) qtab[((size_t)pose * T + tile) * 4u + (uint32_t)q] = NONE;  // not known to be uniform
     if (bx < width) {
       const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
 #pragma unroll
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
 rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
-                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out) {
+                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out, uint32_t *qtab) {
   const uint32_t n = n_poses;
   const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)((tiles_x * tiles_y + (int)RASTER_WAVES - 1) / (int)RASTER_WAVES);  // RASTER_WAVES tiles per workgroup
   if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
@@ -536,7 +541,7 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
   auto rk = dbg.raster_stats ? raster_wave_kernel<true> : raster_wave_kernel<false>;
   hipLaunchKernelGGL(rk, dim3((uint32_t)nblocks), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow, vis, vis16 ? 1u : 0u, prim_out, dbg.no_cover ? 1u : 0u,
-                     d_stats);
+                     qtab, d_stats);
   if (d_stats) {
     unsigned long long h[16];
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));

@@ -49,6 +49,9 @@ struct rdoom_batch {
   uint2 *d_fix_list = nullptr;
   uint32_t fix_cap = 1u << 20;
   uint32_t *d_counts = nullptr, *d_vis = nullptr, *d_prim = nullptr;
+  void *d_frag_const = nullptr;  // the fragment kernel's rarely read constants (fragment.hip: FragConst), written on first use
+  bool frag_const_ready = false;
+  uint32_t *d_qtab = nullptr;  // per (pose, tile, quadrant): the record every pixel of the quadrant shows, or NONE (rasteriser -> fragment kernel)
   uint32_t *d_ghist = nullptr;  // counting sort of the set-up: per pose, one counter per depth bucket
   uint8_t *d_fb = nullptr;
   PoseConst *h_poses = nullptr;  // pinned staging for the per-pose constants
@@ -322,7 +325,7 @@ void rdoom_batch_destroy(rdoom_batch *b) {
   if (!b) return;
   for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_visible, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries, (void *)b->d_hits,
                   (void *)b->d_overflow, (void *)b->d_ghist, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
-                  (void *)b->d_prim, (void *)b->d_fb})
+                  (void *)b->d_prim, (void *)b->d_fb, (void *)b->d_qtab, b->d_frag_const})
     if (p) (void)hipFree(p);
   for (auto &e : b->ev)
     if (e) (void)hipEventDestroy(e);
@@ -371,6 +374,8 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_ghist, setup_histogram_bytes(max_poses));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, (b->vis16 ? sizeof(uint16_t) : sizeof(uint32_t)) * npx);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
+  if (e == hipSuccess) e = hipMalloc(&b->d_frag_const, fragment_const_bytes());
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_qtab, sizeof(uint32_t) * 4u * (size_t)b->n_tiles * max_poses);
   if (e == hipSuccess) {  // sky.frag:13's ndc per column / row, same two operations as the per-pixel form
     std::vector<float> ndc(width + height);
     for (uint32_t i = 0; i < width; i++) ndc[i] = ((float)i + 0.5f) / (0.5f * (float)width) - 1.0f;
@@ -467,12 +472,13 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   if (marks) HIP_TRY(hipEventRecord(ev[1], st));
   uint32_t *prim_out = b->want_prim ? b->d_prim : nullptr;
   if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, W, H, tiles_x, tiles_y,
-                                      b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out))
+                                      b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out, b->d_qtab))
     return rs;
   if (marks) HIP_TRY(hipEventRecord(ev[2], st));
   if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, b->d_poses, W, H, tiles_x,
                                         tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16,
-                                        prim_out, b->d_ndc, b->d_fb, b->d_fix_count, b->d_fix_list, b->fix_cap))
+                                        prim_out, b->d_ndc, b->d_fb, b->d_fix_count, b->d_fix_list, b->fix_cap, b->d_qtab, b->d_frag_const,
+                                        &b->frag_const_ready))
     return rs;
   HIP_TRY(hipGetLastError());
   if (profiled) {

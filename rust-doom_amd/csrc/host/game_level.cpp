@@ -2,6 +2,7 @@
 #include "game_level.hpp"
 
 #include <cmath>
+#include <chrono>
 #include <cstring>
 
 namespace rdoom::game {
@@ -182,9 +183,18 @@ std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, 
                                         TessellateSegsFn tessellate_segs, wad::LevelVisitor *chained) {
   const Archive &archive = *w.archive;
   const TextureDirectory &tex = w.textures;
+  using Clock = std::chrono::steady_clock;
+  auto ms_since = [](Clock::time_point t0) { return std::chrono::duration<float, std::milli>(Clock::now() - t0).count(); };
+  auto t0 = Clock::now();
   const Level level = Level::from_archive(archive, level_index);
+  const float level_lumps_ms = ms_since(t0);
+  t0 = Clock::now();
   const LevelAnalysis analysis(level, archive.metadata());
+  const float analysis_ms = ms_since(t0);
   auto out = std::make_unique<BuiltLevel>();
+  out->timings.level_lumps_ms = level_lumps_ms;
+  out->timings.analysis_ms = analysis_ms;
+  t0 = Clock::now();
 
   // which names feed which atlas (game/src/game_shaders.rs:282-356)
   std::vector<WadName> flat_names, wall_names, decor_names;
@@ -232,6 +242,8 @@ std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, 
   if (tex.num_colormaps() < 32) throw WadError(RDOOM_CORRUPT_WAD, "COLORMAP has fewer than 32 maps");
   out->colormap.assign(tex.colormap(0), tex.colormap(0) + 32 * 256);
 
+  out->timings.atlases_ms = ms_since(t0);
+  t0 = Clock::now();
   Builder builder(materials);
   LevelVisitor no_second;
   VisitorChain chain(builder, chained ? *chained : no_second);  // builder.chain(..): level.rs:378-382
@@ -287,6 +299,7 @@ std::unique_ptr<BuiltLevel> build_level(const LoadedWad &w, size_t level_index, 
   out->counters.num_objects = (uint32_t)std::max<size_t>(1, analysis.num_objects());
   out->counters.num_lights = (uint32_t)out->lights.size();
   out->floor_centroids = std::move(builder.floor_centroids);
+  out->timings.walk_ms = ms_since(t0);
   return out;
 }
 

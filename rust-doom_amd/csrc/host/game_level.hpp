@@ -47,6 +47,7 @@ class Builder : public wad::LevelVisitor {  // game/src/level.rs:307-327, 648-79
   std::vector<rdoom_sprite_vertex> decor_vertices;
   std::map<uint32_t, Indices> object_indices;  // VecMap<Indices>: ascending object id
   rdoom_counters counters{};
+  rdoom_host_timings timings{};  // level_lumps_ms, atlases_ms, analysis_ms, walk_ms of this build
   std::vector<float> floor_centroids;  // xyz per floor polygon (pose generators)
 
  private:
@@ -76,12 +77,14 @@ struct BuiltLevel {
   float start_pos[3] = {0, 0, 0};
   float start_yaw = 0.0f;
   rdoom_counters counters{};
+  rdoom_host_timings timings{};  // level_lumps_ms, atlases_ms, analysis_ms, walk_ms of this build
   std::vector<float> floor_centroids;
 };
 
 struct LoadedWad {
   std::unique_ptr<wad::Archive> archive;
   wad::TextureDirectory textures;
+  rdoom_host_timings timings{};  // open_ms, textures_ms
 };
 
 // WadSystem::create's level half + GameShaders::load_level + Builder::build.

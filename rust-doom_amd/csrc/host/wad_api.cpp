@@ -1,4 +1,5 @@
 // C ABI of the loader + builder (include/rdoom.h "loader + builder"): exceptions stop here.
+#include <chrono>
 #include <cstring>
 
 #include "game_level.hpp"
@@ -146,15 +147,26 @@ rdoom_status rdoom_wad_open(const char *wad_path, const char *metadata_path, rdo
   if (!wad_path || !metadata_path || !out_wad) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   *out_wad = nullptr;
   return guarded([&]() -> rdoom_status {
+    using Clock = std::chrono::steady_clock;
     auto w = std::make_unique<rdoom_wad>();
+    auto t0 = Clock::now();
     w->w.archive = rdoom::wad::Archive::open(wad_path, metadata_path);
+    w->w.timings.open_ms = std::chrono::duration<float, std::milli>(Clock::now() - t0).count();
+    t0 = Clock::now();
     w->w.textures = rdoom::wad::TextureDirectory::from_archive(*w->w.archive);
+    w->w.timings.textures_ms = std::chrono::duration<float, std::milli>(Clock::now() - t0).count();
     *out_wad = w.release();
     return RDOOM_OK;
   });
 }
 
 void rdoom_wad_close(rdoom_wad *wad) { delete wad; }
+
+rdoom_status rdoom_wad_timings(const rdoom_wad *wad, rdoom_host_timings *out) {
+  if (!wad || !out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out = wad->w.timings;
+  return RDOOM_OK;
+}
 
 rdoom_status rdoom_wad_num_levels(const rdoom_wad *wad, uint32_t *out) {
   if (!wad || !out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
@@ -260,6 +272,12 @@ rdoom_status rdoom_built_desc(const rdoom_built *built, rdoom_level_desc *d) {
 rdoom_status rdoom_built_counters(const rdoom_built *built, rdoom_counters *out) {
   if (!built || !out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   *out = built->b->counters;
+  return RDOOM_OK;
+}
+
+rdoom_status rdoom_built_timings(const rdoom_built *built, rdoom_host_timings *out) {
+  if (!built || !out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out = built->b->timings;
   return RDOOM_OK;
 }
 

@@ -382,3 +382,50 @@ def census(lvl, modelview, projection, time, lights, width, height, ours_index, 
     if detail:
         out['where'] = where
     return out
+
+
+def fragment_exact(oracle, lvl, time, lights, gl_rgb, gl_prim, gl_var):
+    """ZERO-TOLERANCE pin of the fragment stage.  For every pixel SwiftShader drew: the oracle's binary32 fragment code
+    (oracle/raster_oracle.c: oracle_shade_varyings = static.frag:18-28, sprite.frag:15-27, sky.frag:24-25 as restated
+    there) applied to the varyings SwiftShader ITSELF interpolated at that pixel, for the primitive that won THERE, must
+    give the colour SwiftShader wrote -- no jitter, no envelope, no classifier.  Returns the counts:
+      pixels    drawn pixels compared
+      disagree  pixels whose colour differs (RGB through PLAYPAL 0, as GL writes it), or that the alpha test would have
+                discarded although GL drew them
+      by_kind   the disagreements per primitive kind
+    `oracle`: oracle.raster.RasterOracle of the level; gl_prim / gl_var: the auxiliary passes of tests/gl_readback.py."""
+    g = (lambda k, d=None: lvl.get(k, d)) if isinstance(lvl, dict) else (lambda k, d=None: getattr(lvl, k, d))
+    playpal = np.asarray(g('palette'), np.uint8).reshape(-1, 3)[:256]
+    out = oracle.shade_varyings(time, lights, gl_prim, gl_var)
+    drawn = out != 0xFFFF
+    kept = drawn & (out < 0x100)
+    rgb = np.zeros(gl_rgb.shape, np.uint8)
+    rgb[kept] = playpal[out[kept]]
+    bad = drawn & (~kept | (rgb != gl_rgb).any(axis=-1))
+    draws = np.asarray(g('draws')).reshape(-1, 4)
+    first = np.cumsum([0] + [int(c) // 3 for c in draws[:, 3]])
+    kinds = draws[np.clip(np.searchsorted(first, gl_prim[bad], side='right') - 1, 0, len(draws) - 1), 0]
+    by_kind = {name: int((kinds == k).sum()) for k, name in ((KIND_FLAT, 'flat'), (KIND_WALL, 'wall'), (KIND_DECOR, 'decor'), (KIND_SKY, 'sky'))}
+    # Sky disagreements: sky.frag hands `uv` straight to a REPEAT / NEAREST sampler, whose texel ADDRESS arithmetic GL leaves
+    # to the implementation (SwiftShader quantises the normalised coordinate to 16 fractional bits: 1/256 of a texel of the
+    # 256-texel-wide sky).  Such a pixel counts as explained only if the coordinate lies within 1/64 texel of a texel
+    # boundary AND the neighbouring texel across that boundary gives exactly the colour GL wrote.
+    sky_explained = 0
+    if by_kind['sky']:
+        sky = np.asarray(g('sky_texture'))
+        sh, sw = sky.shape
+        cmap0 = np.asarray(g('colormap')).reshape(32, 256)[0]
+        all_kinds = draws[np.clip(np.searchsorted(first, gl_prim, side='right') - 1, 0, len(draws) - 1), 0]
+        for y, x in zip(*np.nonzero(bad & (all_kinds == KIND_SKY) & (gl_prim != 0xFFFFFFFF))):
+            u, v = float(gl_var[y, x, 0]), float(gl_var[y, x, 1])
+            fx, fy = (u - math.floor(u)) * sw, (v - math.floor(v)) * sh
+            near = []
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    if (dx and abs(fx - round(fx)) > 1.0 / 64) or (dy and abs(fy - round(fy)) > 1.0 / 64):
+                        continue
+                    ix, iy = int(math.floor(fx + dx * 1.0 / 32)) % sw, int(math.floor(fy + dy * 1.0 / 32)) % sh
+                    near.append(tuple(int(c) for c in playpal[cmap0[int(sky[iy, ix]) & 255]]))
+            sky_explained += tuple(int(c) for c in gl_rgb[y, x]) in near
+    return {'pixels': int(drawn.sum()), 'disagree': int(bad.sum()), 'by_kind': by_kind, 'sky_sampler_boundary': int(sky_explained),
+            'mask': bad}

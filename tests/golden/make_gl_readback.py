@@ -189,7 +189,26 @@ def extended_census(lv, glref, oracle, pose, w, h, obj_seed=None):
     gid = glref.render(mv, pr, t, lights, w, h, mode='ids', object_modelviews=om)
     var = glref.render(mv, pr, t, lights, w, h, mode='varyings', object_modelviews=om)
     fb, prim = oracle.render(mv, pr, t, lights, w, h, want_prim=True, object_modelviews=om)
-    return gl_census.census(lv, mv, pr, t, lights, w, h, fb, prim, rgb, gid, var, object_modelviews=om)
+    c = gl_census.census(lv, mv, pr, t, lights, w, h, fb, prim, rgb, gid, var, object_modelviews=om)
+    c['fragment_exact'] = frag_exact_counts(oracle, lv, t, lights, rgb, gid, var)
+    return c
+
+
+def frag_exact_counts(oracle, lv, t, lights, rgb, gid, var):
+    """the zero-tolerance fragment-stage pin (tests/gl_census.py: fragment_exact), counts only"""
+    r = gl_census.fragment_exact(oracle, lv, t, lights, rgb, gid, var)
+    return {k: r[k] for k in ('pixels', 'disagree', 'by_kind', 'sky_sampler_boundary')}
+
+
+def fragment_exact_total(frames):
+    tot = {'pixels': 0, 'disagree': 0, 'sky_sampler_boundary': 0, 'by_kind': {'flat': 0, 'wall': 0, 'decor': 0, 'sky': 0}}
+    for f in frames.values():
+        fe = f['fragment_exact']
+        for k in ('pixels', 'disagree', 'sky_sampler_boundary'):
+            tot[k] += fe[k]
+        for k in tot['by_kind']:
+            tot['by_kind'][k] += fe['by_kind'][k]
+    return tot
 
 
 def extended_level(levels, key):
@@ -225,6 +244,7 @@ def main():
         var = gls[index].render(mv, pr, t, lights, w, h, mode='varyings', object_modelviews=om)
         fb, prim = oracles[index].render(mv, pr, t, lights, w, h, want_prim=True, object_modelviews=om)
         c = gl_census.census(lv, mv, pr, t, lights, w, h, fb, prim, rgb, gid, var, object_modelviews=om)
+        c['fragment_exact'] = frag_exact_counts(oracles[index], lv, t, lights, rgb, gid, var)
         c.update(level=index, width=w, height=h, time=t, objects_seed=obj_seed)
         census['frames'][key] = c
         arrays[key + '_rgb'] = rgb
@@ -233,6 +253,8 @@ def main():
         print(key, {k: v for k, v in c.items() if k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES})
     tot = {k: sum(f[k] for f in census['frames'].values()) for k in ('pixels', 'mismatch', 'winner_mismatch') + gl_census.CLASSES}
     census['total'] = tot
+    census['fragment_exact_total'] = fragment_exact_total(census['frames'])
+    print('fragment stage, zero tolerance:', census['fragment_exact_total'])
     print('total', tot, 'mismatch fraction %.4f' % (tot['mismatch'] / tot['pixels']))
     # Extended census: counts only (no readbacks are stored for these frames), a wider net for systematic differences --
     # every 32nd pose of the benchmark sweep at 1920x1080, eight poses of each other level's sweep at 640x400, time-varying
@@ -248,6 +270,8 @@ def main():
         print(key, {k: v for k, v in c.items() if k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES})
     etot = {k: sum(f[k] for f in census['extended'].values()) for k in ('pixels', 'mismatch', 'winner_mismatch') + gl_census.CLASSES}
     census['extended_total'] = etot
+    census['extended_fragment_exact_total'] = fragment_exact_total(census['extended'])
+    print('fragment stage, zero tolerance (extended):', census['extended_fragment_exact_total'])
     print('extended total', etot, 'mismatch fraction %.4f' % (etot['mismatch'] / etot['pixels']))
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, 'frames.npz'), **arrays)

@@ -66,3 +66,36 @@ def test_big_level_frames(big, width, height, n):
         if d != (0, 0):
             bad.append((i, d))
     assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+def test_big_level_4k_time_varying_with_per_pose_lights(big):
+    """BASELINE config 5's own configuration on its stand-in: the 10 x E1M1 level at 3840 x 2160, pose i at its own time
+    (animated flats / walls, scrolling walls) with its own light table fill_buffer_at(time) -- the line `bench.py --big
+    --width 3840 --height 2160 --time-varying` measures.  Frames and winning primitive ids against the oracle."""
+    import importlib
+    sharding = importlib.import_module('rust-doom_amd.sharding')
+    path, lv = big
+    built = rd.Wad(path, META_PATH).build_level(0, gpu_tessellation=True)
+    width, height, n = 3840, 2160, 4
+    poses = sharding.pose_sweep(rd, built, n, width, height, first=37)
+    times = np.array([(37 + 64 * i) / 35.0 for i in range(n)], np.float32)   # pose i of the sweep at time i / 35 s, spread out
+    poses['time'] = times
+    lights = np.stack([built.lights_at(float(t)) for t in times])
+    assert len({li.tobytes() for li in lights}) > 1                          # the tables really differ
+    batch = rd.Batch(rd.DeviceLevel(built), width, height, n)
+    batch.enable_primitive_ids()
+    batch.render(poses, lights)
+    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    ro = raster.RasterOracle(lv)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(i):
+        assert lights[i].tobytes() == lv.lights.fill_buffer_at(float(times[i])).tobytes()
+        return ro.render(poses[i]['modelview'], poses[i]['projection'], float(times[i]), lights[i], width, height, want_prim=True)
+
+    with ThreadPoolExecutor(n) as ex:   # (the C oracle releases the GIL: one pose per host thread)
+        want = list(ex.map(one, range(n)))
+    for i, (ofb, oprim) in enumerate(want):
+        assert int((oprim != prim[i]).sum()) == 0 and int((ofb != fb[i]).sum()) == 0, i
+        assert (fb[i] != 0).mean() > 0.5

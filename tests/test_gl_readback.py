@@ -17,7 +17,12 @@ What is asserted:
   * the oracle reproduces the committed census pixel for pixel (no SwiftShader needed: runs anywhere);
   * where SwiftShader and the reference checkout are present (this container), the readbacks and the census are
     regenerated from the reference's shader files and must equal the committed ones;
-  * (gpu) the HIP renderer's frames have exactly the oracle's mismatch sets against the GL readbacks.
+  * (gpu) the HIP renderer's frames have exactly the oracle's mismatch sets against the GL readbacks;
+  * the FRAGMENT STAGE with zero tolerance (gl_census.fragment_exact): the oracle's binary32 fragment code on the varyings
+    SwiftShader itself interpolated, for the primitive that won there, reproduces SwiftShader's colour at EVERY drawn
+    pixel of every frame -- 0 disagreements on flats, walls and decorations (9.7 M stored + 131 M extended pixels); the only
+    disagreements are sky pixels within 1/64 texel of a texel boundary of sky.frag's REPEAT / NEAREST fetch, whose address
+    arithmetic GL leaves to the sampler (38 stored pixels), each reproduced through the neighbouring texel.
 
 Bounds (measured: 0.84 % of the 10 982 400 stored pixels and 0.44 % of the 135 731 200 extended ones differ; 95 % of those
 are texel-boundary picks caused by SwiftShader's ~13-bit perspective interpolation, 2.4 % lie on primitive edges; winners
@@ -83,6 +88,20 @@ def test_extended_census_is_clean_and_bounded():
     assert sum(1 for f in CENSUS['extended'].values() if f['objects_seed'] is not None and f['time'] > 0) >= 27
 
 
+def test_fragment_stage_is_exact():
+    """static.frag:18-28 / sprite.frag:15-27 in binary32 on GL's own varyings == GL's colour, at every drawn pixel"""
+    for name, frames in (('fragment_exact_total', CENSUS['frames']), ('extended_fragment_exact_total', CENSUS['extended'])):
+        tot = CENSUS[name]
+        assert tot['by_kind']['flat'] == 0 and tot['by_kind']['wall'] == 0 and tot['by_kind']['decor'] == 0, (name, tot)
+        assert tot['disagree'] == tot['by_kind']['sky'] == tot['sky_sampler_boundary'], (name, tot)
+        assert tot['disagree'] <= 2e-5 * tot['pixels'], (name, tot)
+        assert tot['pixels'] >= 0.85 * sum(f['pixels'] for f in frames.values())   # nearly every pixel of every frame is drawn
+        for k, f in frames.items():
+            fe = f['fragment_exact']
+            assert fe['disagree'] == fe['by_kind']['sky'] == fe['sky_sampler_boundary'], (k, fe)
+    assert CENSUS['fragment_exact_total']['pixels'] >= 9_000_000 and CENSUS['extended_fragment_exact_total']['pixels'] >= 110_000_000
+
+
 def test_census_is_clean_and_bounded():
     tot = CENSUS['total']
     assert tot['other'] == 0
@@ -121,6 +140,9 @@ def test_swiftshader_runs_the_reference_shaders(oracle_levels, key):
     assert got['other'] == 0
     for k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES:
         assert got[k] == c[k], (k, got[k], c[k])
+    fe = gl_census.fragment_exact(raster.RasterOracle(lv), lv, t, lights, rgb, gid, var)
+    assert {k: fe[k] for k in ('pixels', 'disagree', 'by_kind', 'sky_sampler_boundary')} == c['fragment_exact']
+    assert fe['by_kind']['flat'] == fe['by_kind']['wall'] == fe['by_kind']['decor'] == 0 and fe['disagree'] == fe['sky_sampler_boundary']
 
 
 @pytest.mark.skipif(not gl_readback.available(), reason='needs SwiftShader and the reference checkout (/root/reference)')
@@ -135,6 +157,7 @@ def test_swiftshader_extended_census(key):
     assert got['other'] == 0
     for k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES:
         assert got[k] == c[k], (k, got[k], c[k])
+    assert got['fragment_exact'] == c['fragment_exact']
 
 
 @pytest.mark.skipif(not gl_readback.available(), reason='needs the reference checkout (/root/reference)')

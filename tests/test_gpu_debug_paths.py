@@ -7,7 +7,9 @@ process sets its own, they are process-wide).  Every hook selects an equivalent 
   frag_nq=1      one quad per lane in the fragment kernel (default two when the width is a multiple of 8);
   vis32=1        32-bit visibility words (levels with >= 65535 triangles) instead of 16-bit ones;
   no_cover=1     the rasteriser without its depth-only body for quadrant-covering triangles;
-  frag_bw=k      the fragment kernel's wave block is 2^k units wide (default 3: 64 x 8 pixels)."""
+  frag_bw=k      the fragment kernel's wave block is 2^k units wide (default 3: 64 x 8 pixels);
+  no_qtab=1      the fragment kernel ignores the rasteriser's quadrant table ("every pixel of this 32 x 32 quadrant shows
+                 record r") and reads the visibility words of every block, as it did before the table existed."""
 import os
 import re
 import subprocess
@@ -74,6 +76,16 @@ def test_fragment_wave_block_shapes(bw):
     assert bad == 0
     bad, _ = run_child({'frag_bw': bw, 'frag_nq': 1})
     assert bad == 0
+
+
+@pytest.mark.parametrize('hooks', [{'no_qtab': 1}, {'frag_bw': 2}, {'frag_bw': 2, 'no_qtab': 1}, {'frag_bw': 3, 'frag_nq': 1},
+                                   {'frag_bw': 4, 'frag_nq': 1}, {'frag_bw': 2, 'no_bins': 1}, {'frag_bw': 3, 'vis32': 1}])
+def test_quadrant_table_paths(hooks):
+    """the table serves 32-pixel-wide blocks (one quadrant) and 64-pixel-wide ones (two quadrants side by side), with 8- and
+    4-pixel runs per lane; frames whose right / top quadrants are partly outside (1000 x 520 = 15.6 x 8.1 tiles)"""
+    for args in (('0', '320', '200', '6'), ('0', '1000', '520', '3'), ('3', '712', '296', '3')):
+        bad, _ = run_child(hooks, args)
+        assert bad == 0, (hooks, args)
 
 
 def test_child_case_plain():
