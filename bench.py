@@ -101,6 +101,19 @@ def workload_key(args, levels):
                                                    int(args.time_varying)) + ('|streams=%d' % args.streams if args.streams > 1 else '')
 
 
+def usable_cores():
+    """host threads this process may really run at once: the scheduler affinity, capped by the cgroup's CPU quota (a
+    container on a 256-thread box may be allowed a handful of them; os.cpu_count() would still say 256)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def metric_label(args, levels):
     """BASELINE.json's metric for the default workload; for the others the same quantity with the workload named
     (`config.workload` stays the authoritative description)"""
@@ -283,7 +296,7 @@ def main():
             from oracle import raster
             built, _level, _batch, poses, lights, _stream = work[0]
             ro = raster.RasterOracle(built.arrays())
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             n = min(args.cpu_sample, len(poses))
             sample = np.zeros((n, 33), np.float32)
             sample[:, :16] = poses['modelview'][:n]
@@ -296,7 +309,7 @@ def main():
             # the same scalar loop on ONE thread (a few poses: about a second per megapixel), and the CPU-only geometry
             # build of BASELINE config 1 timed per phase on one thread (tools/dump_geometry.py: t_load = rows a1-a7,
             # t_walk = rows a9-a15 of SURVEY 8(a); medians of 9 runs, no GPU involved)
-            n1 = min(n, max(1, int(round(4.0e6 / frame_px))))
+            n1 = min(n, max(1, int(round(40.0e6 / frame_px))))
             t1 = time.perf_counter()
             ro.render_batch(sample[:n1], li[:n1], args.width, args.height, threads=1)
             t1 = time.perf_counter() - t1
@@ -306,8 +319,8 @@ def main():
             cpu = {'value': round(n * frame_px / tc / 1e6, 3), 'unit': 'Mpixels/s',
                    'cores': min(cores, n), 'kind': 'port',
                    'sample': '%d poses of the same sweep at %dx%d, oracle/raster_oracle.c, %.1f s on %d threads; single thread: '
-                             '%d poses in %.1f s; geometry build: CPU-only C++ path (use_gpu_tessellation = 0), one thread, '
-                             'median of %d runs' % (n, args.width, args.height, tc, min(cores, n), n1, t1, host['repeat']),
+                             '%d poses in %.1f s (os.cpu_count() = %d); geometry build: CPU-only C++ path (use_gpu_tessellation = 0), one thread, '
+                             'median of %d runs' % (n, args.width, args.height, tc, min(cores, n), n1, t1, os.cpu_count() or 1, host['repeat']),
                    't_raster_1': {'value': round(n1 * frame_px / t1 / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1, 'poses': n1},
                    't_load_ms': host['t_load_ms'], 't_walk_ms': host['t_walk_ms'], 'geometry_phases_ms': host['phases_ms'],
                    'geometry_first_run_ms': host['first_run_ms']}

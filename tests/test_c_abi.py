@@ -141,3 +141,15 @@ def test_level_create_rejects_sky_draws_without_a_sky_texture_and_empty_atlases(
     with pytest.raises(rd.RdoomError) as e:
         rd.DeviceLevel(desc)
     assert e.value.status == -1
+
+
+def test_documents_state_the_real_number_of_entry_points():
+    """DESIGN.md / INTEGRATION.md quote how many functions include/rdoom.h declares: the numbers may not drift"""
+    import re
+    n = len(rd.API_SYMBOLS)
+    header = open(os.path.join(ROOT, 'include', 'rdoom.h')).read()
+    assert len(re.findall(r'^(?:rdoom_status|void|const char \*)\s*rdoom_\w+\(', header, flags=re.M)) == n
+    for doc, pattern in (('INTEGRATION.md', r'all (\d+)\s+entry points'), ('DESIGN.md', r'(\d+) C entry points')):
+        text = open(os.path.join(ROOT, doc)).read()
+        found = re.findall(pattern, text)
+        assert found and all(int(x) == n for x in found), (doc, found, n)
