@@ -239,7 +239,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #endif
 constexpr uint32_t RASTER_WAVES = RDOOM_RASTER_WAVES;  // tiles (= waves) per workgroup
 
-template <bool STATS>
+// VIS16: 16-bit visibility words (record indices below 65 535; 0xFFFF = none) -- a compile-time choice: as a run-time
+// flag the compiler kept it as a per-lane boolean and spilled that register to scratch
+// PRIM: the winning primitive ids are written as well (tests; rdoom_batch_enable_primitive_ids)
+template <bool STATS, bool VIS16, bool PRIM>
 __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                              const uint4 *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts, uint32_t cap,
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
                                                              int tiles_y, const uint2 *__restrict__ tile_hdr,
                                                              const uint32_t *__restrict__ entries, uint32_t entry_cap,
                                                              const uint32_t *__restrict__ overflow,
-                                                             uint32_t *__restrict__ vis, uint32_t vis16,
+                                                             uint32_t *__restrict__ vis,
                                                              uint32_t *__restrict__ prim_out, uint32_t no_cover,
                                                              uint32_t *__restrict__ qtab,
                                                              unsigned long long *__restrict__ stats) {
@@ -273,7 +276,8 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   uint32_t *myq = wq[wave];
   // what lane s keeps of the s-th entry of the current batch: record index, quadrant bits (touches: 0..3, covers:
   // 4..7), the depth plane, the nearest depth over each quadrant
-  uint32_t n = 0, myrec = 0, myqb = 0, zpa = 0, zpb = 0, zpc = 0, dnq0 = NONE, dnq1 = NONE, dnq2 = NONE, dnq3 = NONE;
+  // (record index and quadrant bits share one register: a level has fewer than 2^24 triangles, rdoom_level_create checks)
+  uint32_t n = 0, myrq = 0, zpa = 0, zpb = 0, zpc = 0, dnq0 = NONE, dnq1 = NONE, dnq2 = NONE, dnq3 = NONE;
   // Gathers one batch of 64 list entries into the lanes (see the header: candidates, ranking, records, the per-quadrant
   // nearest depths and cover flags).  The usual tile has one batch, gathered once for its four quadrants.
   auto gather = [&](uint32_t base) {
@@ -311,11 +315,11 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // ---- records: lane s gathers entry s -------------------------------------------------------
       const bool have = (uint32_t)lane < n;
-      myrec = 0u, myqb = 0u, zpa = zpb = zpc = 0u, dnq0 = dnq1 = dnq2 = dnq3 = NONE;
+      myrq = 0u, zpa = zpb = zpc = 0u, dnq0 = dnq1 = dnq2 = dnq3 = NONE;
       if (have) {
         const uint32_t e = myq[lane];
-        myrec = e & 0x0FFFFFFFu;
-        myqb = e >> 28;
+        const uint32_t myrec = e & 0x00FFFFFFu;
+        uint32_t myqb = e >> 28;
         const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[myrec]);
         const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3];
         const uint2 c4 = *reinterpret_cast<const uint2 *>(rp + 4);
@@ -349,6 +353,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
           myqb |= (cov && !no_cover) ? (16u << qi) : 0u;  // no_cover: test hook
         }
         dnq0 = dn[0], dnq1 = dn[1], dnq2 = dn[2], dnq3 = dn[3];
+        myrq = myrec | (myqb << 24);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -370,8 +375,8 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       // wins all 1024 pixels without a compare (extremes of the computed depth sit at corners; strictness rules out
       // ties).  Nothing is initialised for such a quadrant; the visibility words are one broadcast value.
       const uint32_t dnq_s = q == 0 ? dnq0 : (q == 1 ? dnq1 : (q == 2 ? dnq2 : dnq3));
-      const unsigned long long touch_s = __ballot(((myqb >> q) & 1u) != 0u);
-      const unsigned long long cover_s = __ballot(((myqb >> (4 + q)) & 1u) != 0u);
+      const unsigned long long touch_s = __ballot(((myrq >> (24 + q)) & 1u) != 0u);
+      const unsigned long long cover_s = __ballot(((myrq >> (28 + q)) & 1u) != 0u);
       if (touch_s != 0ull) {
         const uint32_t s0 = (uint32_t)__builtin_ctzll(touch_s);
         if ((cover_s >> s0) & 1ull) {
@@ -382,23 +387,23 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
           const float zf0 = fmaf(za0, pos(za0) ? xh : xl, fmaf(zb0, pos(zb0) ? yh : yl, zc0));  // in [0, 1]: the entry covers
           const uint32_t df0 = __float2uint_rz(fmaf(zf0, 16777215.0f, 0.5f));
           if ((__ballot(dnq_s <= df0) & touch_s & ~(1ull << s0)) == 0ull) {
-            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)myrec, (int)s0);
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)myrq, (int)s0) & 0xFFFFFFu;
             if (STATS) st[0] += (unsigned long long)__popcll(touch_s), st[9]++;
             // the quadrant table: "all 1024 pixels show record r0" -- the fragment kernel's waves then take the record
             // by scalar loads without reading (or comparing) the visibility words of this quadrant
             if (qtab && lane == 0) qtab[((size_t)pose * T + tile) * 4u + (uint32_t)q] = r0;
             if (bx < width) {
               const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
-              const uint32_t p0 = prim_out ? (prec[r0].r.flags & 0xFFFFFFu) : 0u;
+              const uint32_t p0 = PRIM ? (prec[r0].r.flags & 0xFFFFFFu) : 0u;
 #pragma unroll
               for (int ry = 0; ry < 4; ry++) {
                 if (by + ry < height) {
                   const size_t o = o0 + (size_t)(ry * width);
-                  if (vis16)
+                  if (VIS16)
                     *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) = make_uint2(r0 | (r0 << 16), r0 | (r0 << 16));
                   else
                     *reinterpret_cast<uint4 *>(vis + o) = make_uint4(r0, r0, r0, r0);
-                  if (prim_out) *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p0, p0, p0, p0);
+                  if (PRIM) *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p0, p0, p0, p0);
                 }
               }
             }
@@ -422,11 +427,11 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       if (n == 0u) continue;
       // ---- walk: the entries that touch this quadrant, near to far -------------------------------------------
       const uint32_t dnq = q == 0 ? dnq0 : (q == 1 ? dnq1 : (q == 2 ? dnq2 : dnq3));
-      const unsigned long long qcm = __ballot(((myqb >> (4 + q)) & 1u) != 0u);
+      const unsigned long long qcm = __ballot(((myrq >> (28 + q)) & 1u) != 0u);
       // An entry is hidden in the whole quadrant when its nearest depth over the quadrant (lane s holds entry s's) is
       // beyond the farthest depth ANY lane still holds: all entries are tested at once against that wave-wide maximum,
       // again whenever a body has brought some lane's depths nearer.
-      const unsigned long long touch = __ballot(((myqb >> q) & 1u) != 0u);
+      const unsigned long long touch = __ballot(((myrq >> (24 + q)) & 1u) != 0u);
       uint32_t wave_far = wave_max_u32(lane_far);
       unsigned long long wm = touch & __ballot(dnq <= wave_far);
       if (STATS) st[0] += (unsigned long long)__popcll(touch), st[15] += (unsigned long long)__popcll(touch & ~wm);
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
         auto bc = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)s); };
         auto bf = [&](uint32_t v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, (int)s)); };
         const float za = bf(zpa), zb = bf(zpb), zc = bf(zpc);
-        const uint32_t ridx = bc(myrec);
+        const uint32_t ridx = bc(myrq) & 0xFFFFFFu;
         if ((qcm >> s) & 1ull) {
           // the triangle covers the whole quadrant, inside its bbox, the depth range and in front of the eye, texture
           // rectangle opaque: depth compares only.  (Lanes whose block is hidden lose every compare.)  A depth tie
@@ -501,14 +506,14 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       for (int ry = 0; ry < 4; ry++) {
         if (by + ry < height) {
           const size_t o = o0 + (size_t)(ry * width);
-          if (vis16)  // record indices fit 16 bits (0xFFFF = none): half the visibility traffic
+          if (VIS16)  // record indices fit 16 bits (0xFFFF = none): half the visibility traffic
             *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) =
                 make_uint2(__builtin_amdgcn_perm(best_r[ry * 4 + 1], best_r[ry * 4], 0x05040100u),
                            __builtin_amdgcn_perm(best_r[ry * 4 + 3], best_r[ry * 4 + 2], 0x05040100u));
           else
             *reinterpret_cast<uint4 *>(vis + o) =
                 make_uint4(best_r[ry * 4], best_r[ry * 4 + 1], best_r[ry * 4 + 2], best_r[ry * 4 + 3]);
-          if (prim_out) {
+          if (PRIM) {
             uint32_t p[4];
 #pragma unroll
             for (int rx = 0; rx < 4; rx++)
@@ -538,9 +543,14 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
     HIP_TRY(hipMalloc((void **)&d_stats, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
   }
-  auto rk = dbg.raster_stats ? raster_wave_kernel<true> : raster_wave_kernel<false>;
+  auto pick = [&](auto stats) {
+    constexpr bool S = decltype(stats)::value;
+    return vis16 ? (prim_out ? raster_wave_kernel<S, true, true> : raster_wave_kernel<S, true, false>)
+                 : (prim_out ? raster_wave_kernel<S, false, true> : raster_wave_kernel<S, false, false>);
+  };
+  auto rk = dbg.raster_stats ? pick(std::true_type{}) : pick(std::false_type{});
   hipLaunchKernelGGL(rk, dim3((uint32_t)nblocks), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
-                     tiles_y, tile_hdr, entries, entry_cap, overflow, vis, vis16 ? 1u : 0u, prim_out, dbg.no_cover ? 1u : 0u,
+                     tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, dbg.no_cover ? 1u : 0u,
                      qtab, d_stats);
   if (d_stats) {
     unsigned long long h[16];
