@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALG_READ_BYTES_PER_PIXEL = 6   # 4 B visibility record + 2 B atlas texel
+LAYOUT_READ_BYTES_PER_PIXEL = 4  # what this layout stores per pixel: a 16-bit visibility word + a 16-bit texel
 
 
 def parse_args(argv=None):
@@ -352,6 +353,9 @@ def main():
                        'workload_key': workload_key(args, levels), 'kernel_sources': kernel_source_digest()},
             'roofline': {'bound': 'hbm', 'kernel': 'fragment_kernel', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         # frac: SURVEY 8(d)'s 6 B/px; frac_layout_bytes: the 2 + 2 B/px this layout keeps per pixel (the quadrant
+                         # table lets uniform quadrants skip even those); frac_actual_bytes: HBM traffic by the PMC counters
+                         'frac_layout_bytes': round(achieved / HBM_PEAK_GBS * LAYOUT_READ_BYTES_PER_PIXEL / ALG_READ_BYTES_PER_PIXEL, 4),
                          'traffic': traffic, 'frac_actual_bytes': frac_actual},
             'cpu_baseline': cpu,
         }

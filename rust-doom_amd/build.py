@@ -16,6 +16,12 @@ COMMON = ['-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '
           '-Wall', '-Wno-unused-function', '-Wno-bitwise-instead-of-logical']  # bitwise and on bools is deliberate (branch-free)
 
 
+# per-unit extra flags.  raster.hip: LLVM's SLP vectoriser packs the boolean results of independent compares into 16-bit lanes
+# (v_cndmask 0/1, shifts, ors) where four compares and scalar ANDs would do, and the packed fmas it also forms do not make up
+# for it: without it the rasteriser is 1-1.5 % faster on every workload (A/B on one box, profiles/r03_ab.txt)
+UNIT_FLAGS = {'raster.hip': ['-fno-slp-vectorize']}
+
+
 def sources():
     hip = sorted(glob.glob(os.path.join(HERE, 'csrc', 'hip', '*.hip')))
     cpp = sorted(glob.glob(os.path.join(HERE, 'csrc', 'host', '*.cpp')))
@@ -41,7 +47,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
             if src.endswith('.hip'):
-                cmd = [hipcc, '--offload-arch=gfx950', '-x', 'hip'] + COMMON + ['-c', src, '-o', obj]
+                cmd = [hipcc, '--offload-arch=gfx950', '-x', 'hip'] + COMMON + UNIT_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
             else:
                 cmd = [hipcc, '-x', 'c++'] + COMMON + ['-c', src, '-o', obj]
             jobs.append(cmd)

@@ -257,19 +257,23 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __shared__ uint32_t wq[RASTER_WAVES][64];
   __shared__ uint4 wrec[RASTER_WAVES][64][4];  // per wave: 15 words of each of the 64 gathered raster records
-  const uint32_t b = blockIdx.x;
-  const uint32_t T = (uint32_t)(tiles_x * tiles_y), T4 = (T + RASTER_WAVES - 1u) / RASTER_WAVES;
-  const uint32_t g = b >> 3;
-  const uint32_t pose = (g / T4) * 8u + (b & 7u);
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave: an SGPR
-  const uint32_t tile = (g % T4) * RASTER_WAVES + (uint32_t)wave;
-  if (pose >= n_poses || tile >= T) return;
-  const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE_W, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE_H;
+  // grid = (8 tiles_x, tiles_y, pose groups of 8): workgroups are dispatched x-fastest and dealt to the eight XCDs in turn,
+  // so blockIdx.x & 7 is the XCD and all tiles of a pose land on one of them; no division is needed to find (pose, tile)
+  static_assert(RASTER_WAVES == 1, "the 3-D grid maps one tile to one workgroup");
+  const uint32_t T = (uint32_t)(tiles_x * tiles_y);
+  const uint32_t pose = blockIdx.z * 8u + (blockIdx.x & 7u);
+  const int tid = threadIdx.x, wave = 0, lane = tid & 63;
+  const uint32_t tile_x = blockIdx.x >> 3, tile_y = blockIdx.y, tile = tile_y * (uint32_t)tiles_x + tile_x;
+  if (pose >= n_poses) return;
+  const int tx0 = (int)tile_x * TILE_W, ty0 = (int)tile_y * TILE_H;
   const int lx = (lane & 7) * 4, ly = (lane >> 3) * 4;  // this lane's 4x4 block inside a quadrant
   const TriRec *prec = recs + (size_t)pose * cap;
   const uint4 *psorted = sorted + (size_t)pose * cap;
-  const bool binned = overflow[pose] == 0u;  // the pose's per-tile lists are complete
-  const uint2 hdr = binned ? tile_hdr[(size_t)pose * T + tile] : make_uint2(0u, counts[pose]);
+  // (three independent scalar loads in flight at once, not a chain: the header is read whether or not it will be used)
+  const uint32_t over = overflow[pose], all_visible = counts[pose];
+  const uint2 hdr_binned = tile_hdr[(size_t)pose * T + tile];
+  const bool binned = over == 0u;  // the pose's per-tile lists are complete
+  const uint2 hdr = binned ? hdr_binned : make_uint2(0u, all_visible);
   const uint32_t *pent = entries + (size_t)pose * entry_cap + hdr.x;
   const uint32_t count = hdr.y;
   const bool single = count <= 64u;  // the usual case: one gather serves all four quadrants
@@ -535,8 +539,9 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
                            const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out, uint32_t *qtab) {
   const uint32_t n = n_poses;
-  const uint64_t nblocks = (uint64_t)((n + 7) / 8) * 8ull * (uint64_t)((tiles_x * tiles_y + (int)RASTER_WAVES - 1) / (int)RASTER_WAVES);  // RASTER_WAVES tiles per workgroup
-  if (nblocks > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
+  const uint32_t groups = (n + 7u) / 8u;  // pose groups of eight: one pose per XCD
+  if (groups > 65535u || tiles_y > 65535 || (uint64_t)tiles_x * 8ull > 0x7FFFFFFFull)
+    return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
   const rdoom::DebugOptions &dbg = rdoom::debug_options();
   unsigned long long *d_stats = nullptr;
   if (dbg.raster_stats) {
@@ -549,14 +554,14 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
                  : (prim_out ? raster_wave_kernel<S, false, true> : raster_wave_kernel<S, false, false>);
   };
   auto rk = dbg.raster_stats ? pick(std::true_type{}) : pick(std::false_type{});
-  hipLaunchKernelGGL(rk, dim3((uint32_t)nblocks), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
+  hipLaunchKernelGGL(rk, dim3((uint32_t)tiles_x * 8u, (uint32_t)tiles_y, groups), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, dbg.no_cover ? 1u : 0u,
                      qtab, d_stats);
   if (d_stats) {
     unsigned long long h[16];
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     (void)hipFree(d_stats);
-    const double waves = (double)((n + 7) / 8) * 8.0 * (double)(tiles_x * tiles_y) * 4.0;  // (pose, quadrant) passes
+    const double waves = (double)groups * 8.0 * (double)(tiles_x * tiles_y) * 4.0;  // (pose, quadrant) passes
     fprintf(stderr,
             "[rdoom stats] per quadrant pass: queue %.1f  past quadrant early-z %.1f  quadrant-cover %.2f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
             "  general %.3f (lanes %.1f: masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | one-entry shortcut %.3f\n",

@@ -196,3 +196,16 @@ def test_hip_against_committed_gl_readback(wad_path, oracle_levels):
             batch.render(pose, built.lights_at(t), object_modelviews=None if om is None else om[None])
             fb, prim = batch.read_framebuffer()[0], batch.read_primitive_ids()[0]
             assert mismatch_counts(lv, key, fb, prim) == (c['mismatch'], c['winner_mismatch']), key
+            # not just the same COUNTS: the same pixels -- the HIP frame and its winners are the oracle's, so its mismatch
+            # mask against the GL readback is the one the census classified pixel by pixel
+            ofb, oprim = raster.RasterOracle(lv).render(mv, pr, t, lights, c['width'], c['height'], want_prim=True, object_modelviews=om)
+            pal = np.asarray(lv.palette, np.uint8).reshape(256, 3)
+            gl_rgb, gl_prim = FRAMES[key + '_rgb'], FRAMES[key + '_prim']
+
+            def masks(f, p):
+                rgb = pal[f]
+                rgb[p == 0xFFFFFFFF] = gl_readback.CLEAR_RGB
+                return (rgb != gl_rgb).any(-1), (p & 0xFFFFFF) != (gl_prim & 0xFFFFFF)
+
+            for got, want in zip(masks(fb, prim), masks(ofb, oprim)):
+                assert np.array_equal(got, want), key

@@ -28,7 +28,10 @@ tail -1 $OUT/bench_plain.json
 : > $OUT/bench_other.jsonl
 for ARGS in "--width 3840 --height 2160 --poses 256" "--width 1280 --height 720 --poses 2048" "--width 320 --height 200 --poses 8192" \
             "--big" "--big --width 3840 --height 2160 --poses 256 --time-varying" "--levels 0-8 --poses 512" \
-            "--gpus 2" "--gpus 2 --scaling strong"; do
+            "--streams 2" "--gpus 2" "--gpus 2 --scaling strong"; do
   python bench.py $ARGS --steps 10 --warmup 2 --cpu-sample 0 2>/dev/null | grep '^{' | tail -1 >> $OUT/bench_other.jsonl
 done
 wc -l $OUT/bench_other.jsonl
+# 4. issue-slot / occupancy counters of the hot kernels on the final device sources
+bash tools/pmc_frag.sh $TAG/issue > $OUT/issue.log 2>&1
+find $OUT/issue -name '*counter_collection.csv' | wc -l
