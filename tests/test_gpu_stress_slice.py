@@ -2,7 +2,7 @@
 length by hand (those scripts stay for long runs): every synthetic level, random poses / times / pitches / per-object
 offsets, and poses the ordinary sweep rarely produces -- eyes within centimetres of walls and on floor planes, far
 outside the level, straight up / down.  HIP vs oracle, palette-index framebuffers AND winning primitive ids, bit for bit.
-About 330 poses in all."""
+About 700 poses in all."""
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -36,11 +36,12 @@ def compare(lv, poses, lights, w, h, om=None):
     return float(np.mean(prim != 0xFFFFFFFF))
 
 
+@pytest.mark.parametrize('seed', [0, 1, 2])
 @pytest.mark.parametrize('index', range(9))
-def test_random_poses_times_and_moving_objects(oracle_levels, index):
+def test_random_poses_times_and_moving_objects(oracle_levels, index, seed):
     lv, n = oracle_levels(index), 20
-    rng = np.random.RandomState(100 + index)
-    w, h = SIZES[index % len(SIZES)]
+    rng = np.random.RandomState(100 + index + 1000 * seed)
+    w, h = SIZES[(index + seed) % len(SIZES)]
     tri = lv.static_vertices['a_pos'][lv.static_indices.reshape(-1, 3)].mean(1)
     n_obj = int(lv.num_objects)
     poses, om, lights = np.zeros(n, rd.POSE), np.zeros((n, n_obj, 16), np.float32), np.zeros((n, 256), np.uint8)
