@@ -5,7 +5,7 @@
 # usage (GPU box, repo root): tools/pmc_frag.sh <out_subdir> [bench args...]; summarise with tools/pmc_summary.py
 set -u
 OUT=gpurun_out/${1:-pmcf}; shift || true
-ARGS=${@:---poses 256 --steps 1 --warmup 1 --cpu-sample 0}
+ARGS=${@:---streams 1 --poses 256 --steps 1 --warmup 1 --cpu-sample 0}
 export TMPDIR=/tmp
 mkdir -p $OUT
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
