@@ -367,6 +367,48 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   asm volatile("" ::: "memory");
   if (single && count != 0u) gather(0u);
 #endif
+#ifndef RDOOM_NO_TILE_SHORTCUT
+  // The same shortcut one level up: the tile's nearest entry (lane 0: the list is ranked) covers all four quadrants and
+  // every other entry lies, in every quadrant it touches, strictly behind that entry's farthest depth over the whole tile.
+  // (A tile that crosses the frame's edge never qualifies: cover needs the bbox, which is clipped to the frame.)
+  if (single && n != 0u) {
+    const uint32_t rq0 = (uint32_t)__builtin_amdgcn_readlane((int)myrq, 0);
+    if ((rq0 >> 28) == 0xFu) {
+      const float za0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpa, 0)),
+                  zb0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpb, 0)),
+                  zc0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpc, 0));
+      const float xl = (float)tx0 + 0.5f, xh = (float)tx0 + 63.5f, yl = (float)ty0 + 0.5f, yh = (float)ty0 + 63.5f;
+      const float zf0 = fmaf(za0, pos(za0) ? xh : xl, fmaf(zb0, pos(zb0) ? yh : yl, zc0));  // in [0, 1]: the entry covers
+      const uint32_t df0 = __float2uint_rz(fmaf(zf0, 16777215.0f, 0.5f));
+      // my entry's nearest depth over the quadrants it touches (lanes without an entry hold NONE everywhere)
+      const uint32_t tq = myrq >> 24;
+      const uint32_t near_all = min(min((tq & 1u) ? dnq0 : NONE, (tq & 2u) ? dnq1 : NONE), min((tq & 4u) ? dnq2 : NONE, (tq & 8u) ? dnq3 : NONE));
+      if ((__ballot(near_all <= df0) & ~1ull) == 0ull) {
+        const uint32_t r0 = rq0 & 0xFFFFFFu;
+        const uint32_t p0 = PRIM ? (prec[r0].r.flags & 0xFFFFFFu) : 0u;
+        if (STATS) st[0] += (unsigned long long)n, st[9] += 4ull;
+        if (qtab && lane < 4) qtab[((size_t)pose * T + tile) * 4u + (uint32_t)lane] = r0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int bx = tx0 + (q & 1) * 32 + lx, by = ty0 + (q >> 1) * 32 + ly;
+          const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
+#pragma unroll
+          for (int ry = 0; ry < 4; ry++) {
+            const size_t o = o0 + (size_t)(ry * width);
+            if (VIS16)
+              *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) = make_uint2(r0 | (r0 << 16), r0 | (r0 << 16));
+            else
+              *reinterpret_cast<uint4 *>(vis + o) = make_uint4(r0, r0, r0, r0);
+            if (PRIM) *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p0, p0, p0, p0);
+          }
+        }
+        if (STATS && lane == 0)
+          for (int k = 0; k < 16; k++) atomicAdd(&stats[k], st[k]);
+        return;
+      }
+    }
+  }
+#endif
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
     const int qx0 = tx0 + (q & 1) * 32, qy0 = ty0 + (q >> 1) * 32;  // this quadrant
