@@ -88,6 +88,16 @@ def test_quadrant_table_paths(hooks):
         assert bad == 0, (hooks, args)
 
 
+@pytest.mark.parametrize('size', [(8, 8), (64, 64), (128, 64), (1024, 512), (1920, 1088), (12, 300), (2052, 36)])
+def test_frame_sizes_around_the_tile_grid(size):
+    """frames that are one tile, whole tiles only (the tile-level shortcut can fire on every tile), narrower than a quadrant,
+    or a strip one tile high; width a multiple of 4 but not of 8 takes the one-quad-per-lane fragment variant"""
+    bad, _ = run_child({}, ('0', str(size[0]), str(size[1]), '3'))
+    assert bad == 0, size
+    bad, _ = run_child({'no_qtab': 1}, ('4', str(size[0]), str(size[1]), '2'))
+    assert bad == 0, size
+
+
 def test_child_case_plain():
     bad, fixups = run_child({})
     assert bad == 0 and fixups < 1000
