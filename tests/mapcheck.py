@@ -206,6 +206,20 @@ def concavity_depth(p, sign):
     return float(max(0.0, (sign * d).max()))
 
 
+def thickness(p):
+    """smallest width of the point set p over the directions of its point pairs (map units): a sliver's short side"""
+    p = np.asarray(p, np.float64)
+    best = np.inf
+    for i in range(len(p)):
+        for j in range(i + 1, len(p)):
+            d = p[j] - p[i]
+            ln = np.hypot(d[0], d[1])
+            if ln > 0:
+                w = ((p[:, 0] - p[i, 0]) * d[1] - (p[:, 1] - p[i, 1]) * d[0]) / ln
+                best = min(best, float(w.max() - w.min()))
+    return best
+
+
 def clip_convex(subject, clip):
     """Sutherland-Hodgman: subject polygon clipped to the convex polygon `clip` (both counter-clockwise)"""
     out = [tuple(q) for q in subject]
