@@ -173,7 +173,12 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
       const uint32_t div_m = fc->div_m, div_sh = fc->div_sh;
       const uint32_t qi = mylist[first + j];
       const uint32_t row = fast_div(qi, div_m, div_sh), qx = qi - row * quads_per_row;
-      const uint32_t id = VIS16 ? (uint32_t)pvis16[(size_t)qi * 4u + k] : pvis32[(size_t)qi * 4u + k];
+      // the record of my pixel: from the quadrant table where it has an entry (the rasteriser then wrote no visibility
+      // words for that quadrant), else the pixel's visibility word
+      uint32_t id = NONE;
+      if (qtab_mode != 0u)
+        id = qtab[((size_t)pose * n_tiles + ((row >> 6) * tiles_x + (qx >> 4))) * 4u + ((row >> 5) & 1u) * 2u + ((qx >> 3) & 1u)];
+      if (id == NONE) id = VIS16 ? (uint32_t)pvis16[(size_t)qi * 4u + k] : pvis32[(size_t)qi * 4u + k];
       uint32_t c = 0;
       const uint32_t pix = (row * quads_per_row + qx) * 4u + k;
       if (id != NONE_ID) {
@@ -229,6 +234,7 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
     // qtab_mode 1: the block is 32 pixels wide (inside one quadrant); 2: 64 pixels wide (two quadrants of one tile, side
     // by side -- the right one may lie outside the frame, where the rasteriser writes nothing).
     uint32_t tq = NONE;
+    uint32_t tl = NONE;  // per lane: the entry of the quadrant my pixels lie in, when the block spans two that differ
     if (qtab_mode != 0u) {
       const uint32_t bx0 = (wbx << bw_log2) * (uint32_t)NPX, by0 = wby << (6u - bw_log2);
       const uint32_t *e = qtab + ((size_t)pose * n_tiles + ((by0 >> 6) * tiles_x + (bx0 >> 6))) * 4u + ((by0 >> 5) & 1u) * 2u;
@@ -236,7 +242,11 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         tq = e[(bx0 >> 5) & 1u];
       } else {
         const uint2 two = *reinterpret_cast<const uint2 *>(e);
-        tq = (two.x == two.y || bx0 + 32u >= (uint32_t)width) ? two.x : NONE;
+        const bool same = two.x == two.y || bx0 + 32u >= (uint32_t)width;
+        tq = same ? two.x : NONE;
+#ifndef RDOOM_FRAG_NO_TL  // (A/B builds only: without the per-lane entries every visibility word must be there -- keep_vis)
+        tl = same ? NONE : (((lane_col * (uint32_t)NPX) & 32u) ? two.y : two.x);
+#endif
       }
     }
     tq = (uint32_t)__builtin_amdgcn_readfirstlane((int)tq);
@@ -245,6 +255,9 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
     bool uniform;
     if (table_one) {
       id0 = tq;
+      uniform = true;
+    } else if (tl != NONE) {  // (per lane: my quadrant has an entry, the other one has another or none)
+      id0 = tl;
       uniform = true;
     } else if (VIS16) {
       if (NQ == 2) {
@@ -613,13 +626,30 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
 
 size_t fragment_const_bytes() { return sizeof(FragConst); }
 
+FragmentPlan plan_fragment(int width, int height, bool have_qtab) {
+  (void)height;
+  const rdoom::DebugOptions dbg = rdoom::debug_options();  // test hooks: equivalent paths, same image
+  FragmentPlan p{};
+  p.leak_mod = (uint32_t)std::max(0, dbg.leak_mod);
+  p.nq = (dbg.frag_nq == 2 && width % 8 == 0) ? 2 : 1;  // quads per lane: two when rows divide into 8-pixel runs
+  p.bwl = (uint32_t)std::min(6, std::max(0, dbg.frag_bw));  // log2(units per block row)
+  p.chunk = dbg.frag_chunk > 0 ? (uint32_t)dbg.frag_chunk : (uint32_t)FRAG_CHUNK;
+  // the quadrant table serves blocks that lie inside one 32 x 32 quadrant, or inside two side by side
+  const uint32_t bw = 1u << p.bwl, bh = 64u >> p.bwl, block_px = bw * 4u * (uint32_t)p.nq;
+  p.qtab_mode = (!have_qtab || dbg.no_qtab || bh > 32u) ? 0u : (block_px == 32u ? 1u : (block_px == 64u ? 2u : 0u));
+  // With leak_mod (tests) the kernel sends every block through its visibility words, so they must all be there;
+  // keep_vis (tests, A/B runs) asks for them outright.
+  p.skip_described_vis = p.qtab_mode != 0u && p.leak_mod == 0u && !dbg.keep_vis;
+  return p;
+}
+
 rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                              const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,
                              int width, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
                              const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
                              bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
                              uint2 *fix_list, uint32_t fix_cap, const uint32_t *qtab, void *d_frag_const,
-                             bool *frag_const_ready) {
+                             bool *frag_const_ready, const FragmentPlan &plan) {
   const uint32_t n = n_poses;
   const int W = width, H = height;
   const uint32_t qpr = (uint32_t)W / 4u, qpp = qpr * (uint32_t)H;
@@ -636,13 +666,12 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
         (hi < qpp && (uint32_t)(((uint64_t)hi * div_m) >> 32) >> div_sh != k))
       return rdoom::fail(RDOOM_BAD_ARG, "internal: fast_div constants invalid for width %d", W);
   }
-  const rdoom::DebugOptions &dbg = rdoom::debug_options();  // test hooks: equivalent paths, same image
-  const uint32_t debug_leak_mod = (uint32_t)std::max(0, dbg.leak_mod);
-  const int nq = (dbg.frag_nq == 2 && W % 8 == 0) ? 2 : 1;  // quads per lane: two when rows divide into 8-pixel runs
-  const uint32_t bwl = (uint32_t)std::min(6, std::max(0, dbg.frag_bw));  // log2(units per block row)
+  const uint32_t debug_leak_mod = plan.leak_mod;
+  const int nq = plan.nq;
+  const uint32_t bwl = plan.bwl;
   const uint32_t bw = 1u << bwl, bh = 64u >> bwl;
   const uint32_t wbpr = (qpr / (uint32_t)nq + bw - 1u) / bw, wbpp = wbpr * (((uint32_t)H + bh - 1u) / bh);  // bw-unit x bh-row blocks
-  const uint32_t frag_chunk = dbg.frag_chunk > 0 ? (uint32_t)dbg.frag_chunk : (uint32_t)FRAG_CHUNK;
+  const uint32_t frag_chunk = plan.chunk;
   const uint32_t fblocks = (wbpp + frag_chunk * FRAG_WAVES - 1u) / (frag_chunk * FRAG_WAVES);  // a workgroup = FRAG_WAVES waves x frag_chunk blocks
   HIP_TRY(hipMemsetAsync(fix_count, 0, 2 * sizeof(uint32_t), st));
   const uint64_t fgrid = (uint64_t)((n + 7) / 8) * 8ull * fblocks;
@@ -654,9 +683,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
     frag = nq == 2 ? (vis16 ? fragment_kernel<2, 2, true> : fragment_kernel<2, 2, false>)
                    : (vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>);
 #endif
-  // the quadrant table serves blocks that lie inside one 32 x 32 quadrant, or inside two side by side
-  const uint32_t block_px = bw * 4u * (uint32_t)nq;
-  const uint32_t qtab_mode = (!qtab || dbg.no_qtab || bh > 32u) ? 0u : (block_px == 32u ? 1u : (block_px == 64u ? 2u : 0u));
+  const uint32_t qtab_mode = qtab ? plan.qtab_mode : 0u;
   if (!*frag_const_ready) {  // constant for the life of the batch: written once
     FragConst h{};
     h.lv = lv, h.fix_count = fix_count, h.fix_list = fix_list, h.ndc_tab = ndc_tab, h.fix_cap = fix_cap, h.div_m = div_m, h.div_sh = div_sh;

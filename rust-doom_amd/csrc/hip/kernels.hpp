@@ -31,7 +31,18 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
                            const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out,
-                           uint32_t *qtab);  // qtab (optional): per (pose, tile, quadrant) the record all its pixels show, or NONE
+                           uint32_t *qtab,  // qtab (optional): per (pose, tile, quadrant) the record all its pixels show, or NONE
+                           bool skip_described_vis);  // no visibility words for quadrants the table describes (FragmentPlan)
+// How the fragment kernel will walk a frame of this size, decided ONCE per render from the debug hooks (rasteriser and
+// fragment kernel must agree on who reads the quadrant table): quads per lane, log2(units per block row), blocks per
+// workgroup wave, the test hook leak_mod, and qtab_mode (0: table unused; 1 / 2: a wave block lies in one / two quadrants).
+struct FragmentPlan {
+  int nq;
+  uint32_t bwl, chunk, leak_mod, qtab_mode;
+  // the rasteriser may leave out the visibility words of quadrants the table describes: every reader consults the table first
+  bool skip_described_vis;
+};
+FragmentPlan plan_fragment(int width, int height, bool have_qtab);
 // Kernels 3 + 4: fragment kernel -> palette indices, then the alpha-leak fixup (fragment.hip)
 rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                              const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,
@@ -39,7 +50,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
                              const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
                              bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
                              uint2 *fix_list, uint32_t fix_cap, const uint32_t *qtab, void *d_frag_const,
-                             bool *frag_const_ready);  // d_frag_const: fragment_const_bytes() of device memory owned by the batch
+                             bool *frag_const_ready, const FragmentPlan &plan);  // d_frag_const: fragment_const_bytes() of device memory owned by the batch
 size_t fragment_const_bytes();
 
 }  // namespace rdoom_dev

@@ -242,7 +242,10 @@ constexpr uint32_t RASTER_WAVES = RDOOM_RASTER_WAVES;  // tiles (= waves) per wo
 // VIS16: 16-bit visibility words (record indices below 65 535; 0xFFFF = none) -- a compile-time choice: as a run-time
 // flag the compiler kept it as a per-lane boolean and spilled that register to scratch
 // PRIM: the winning primitive ids are written as well (tests; rdoom_batch_enable_primitive_ids)
-template <bool STATS, bool VIS16, bool PRIM>
+// SKIPVIS: a quadrant the table describes ("all 1024 pixels show record r") gets NO visibility words: the fragment kernel
+// takes the record from the table wherever an entry exists and reads visibility words only where it says NONE
+// (launch_fragment's plan decides; 60 % of the quadrant passes of the 1080p sweep then store four bytes instead of 2 KB)
+template <bool STATS, bool VIS16, bool PRIM, bool SKIPVIS>
 __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                              const uint4 *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts, uint32_t cap,
@@ -388,18 +391,22 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
         const uint32_t p0 = PRIM ? (prec[r0].r.flags & 0xFFFFFFu) : 0u;
         if (STATS) st[0] += (unsigned long long)n, st[9] += 4ull;
         if (qtab && lane < 4) qtab[((size_t)pose * T + tile) * 4u + (uint32_t)lane] = r0;
+        if (!SKIPVIS || PRIM) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int bx = tx0 + (q & 1) * 32 + lx, by = ty0 + (q >> 1) * 32 + ly;
-          const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
+          for (int q = 0; q < 4; q++) {
+            const int bx = tx0 + (q & 1) * 32 + lx, by = ty0 + (q >> 1) * 32 + ly;
+            const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
 #pragma unroll
-          for (int ry = 0; ry < 4; ry++) {
-            const size_t o = o0 + (size_t)(ry * width);
-            if (VIS16)
-              *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) = make_uint2(r0 | (r0 << 16), r0 | (r0 << 16));
-            else
-              *reinterpret_cast<uint4 *>(vis + o) = make_uint4(r0, r0, r0, r0);
-            if (PRIM) *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p0, p0, p0, p0);
+            for (int ry = 0; ry < 4; ry++) {
+              const size_t o = o0 + (size_t)(ry * width);
+              if (!SKIPVIS) {
+                if (VIS16)
+                  *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) = make_uint2(r0 | (r0 << 16), r0 | (r0 << 16));
+                else
+                  *reinterpret_cast<uint4 *>(vis + o) = make_uint4(r0, r0, r0, r0);
+              }
+              if (PRIM) *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p0, p0, p0, p0);
+            }
           }
         }
         if (STATS && lane == 0)
@@ -438,17 +445,19 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
             // the quadrant table: "all 1024 pixels show record r0" -- the fragment kernel's waves then take the record
             // by scalar loads without reading (or comparing) the visibility words of this quadrant
             if (qtab && lane == 0) qtab[((size_t)pose * T + tile) * 4u + (uint32_t)q] = r0;
-            if (bx < width) {
+            if ((!SKIPVIS || PRIM) && bx < width) {
               const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
               const uint32_t p0 = PRIM ? (prec[r0].r.flags & 0xFFFFFFu) : 0u;
 #pragma unroll
               for (int ry = 0; ry < 4; ry++) {
                 if (by + ry < height) {
                   const size_t o = o0 + (size_t)(ry * width);
-                  if (VIS16)
-                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) = make_uint2(r0 | (r0 << 16), r0 | (r0 << 16));
-                  else
-                    *reinterpret_cast<uint4 *>(vis + o) = make_uint4(r0, r0, r0, r0);
+                  if (!SKIPVIS) {
+                    if (VIS16)
+                      *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) = make_uint2(r0 | (r0 << 16), r0 | (r0 << 16));
+                    else
+                      *reinterpret_cast<uint4 *>(vis + o) = make_uint4(r0, r0, r0, r0);
+                  }
                   if (PRIM) *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(p0, p0, p0, p0);
                 }
               }
@@ -467,6 +476,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
     // max of best_d: the farthest depth this lane still holds.  A lane whose block lies outside the frame (partial tiles:
     // the bottom row at 1080 = 16 * 64 + 56) stores nothing and must not keep the wave-wide farthest depth at "none"
     uint32_t lane_far = ((bx >= width) | (by >= height)) ? 0u : NONE;
+    bool had_cover = false;  // (uniform) some entry covers the whole quadrant
 #pragma unroll 1
     for (uint32_t base = 0; base < count; base += 64u) {
       if (!single) gather(base);
@@ -474,6 +484,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       // ---- walk: the entries that touch this quadrant, near to far -------------------------------------------
       const uint32_t dnq = q == 0 ? dnq0 : (q == 1 ? dnq1 : (q == 2 ? dnq2 : dnq3));
       const unsigned long long qcm = __ballot(((myrq >> (28 + q)) & 1u) != 0u);
+      had_cover |= qcm != 0ull;
       // An entry is hidden in the whole quadrant when its nearest depth over the quadrant (lane s holds entry s's) is
       // beyond the farthest depth ANY lane still holds: all entries are tested at once against that wave-wide maximum,
       // again whenever a body has brought some lane's depths nearer.
@@ -545,14 +556,34 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       }
     }
     // ---- this quadrant's visibility words ------------------------------------------------------------------------
-    if (qtab && lane == 0) qtab[((size_t)pose * T + tile) * 4u + (uint32_t)q] = NONE;  // not known to be uniform
-    if (bx < width) {
+    // One record after all?  (The shortcut above needs the winner to lie strictly in front of everything else over the whole
+    // quadrant; a quadrant can still end up with one winner.)  Lane 0's first pixel lies inside the frame; lanes whose block
+    // lies outside it do not count -- the table speaks about the pixels of the frame.
+    uint32_t described = NONE;
+#ifndef RDOOM_NO_LATE_TABLE
+    if (qtab && had_cover) {  // (one winner needs a triangle that covers the quadrant: without one the check is skipped)
+      const uint32_t rf = (uint32_t)__builtin_amdgcn_readfirstlane((int)best_r[0]);
+      uint32_t lo = best_r[0], hi = best_r[0];  // (three-operand min / max: 16 instructions for the 16 winners)
+#pragma unroll
+      for (int k = 1; k < 15; k += 2) {
+        lo = min(lo, min(best_r[k], best_r[k + 1]));
+        hi = max(hi, max(best_r[k], best_r[k + 1]));
+      }
+      lo = min(lo, best_r[15]), hi = max(hi, best_r[15]);
+      const bool outside_lane = (bx >= width) | (by >= height);
+      if (rf != NONE && __all(outside_lane | ((lo == rf) & (hi == rf)))) described = rf;
+    }
+#endif
+    if (qtab && lane == 0) qtab[((size_t)pose * T + tile) * 4u + (uint32_t)q] = described;  // NONE: not known to be uniform
+    const bool want_vis = !SKIPVIS || described == NONE;  // (uniform) a described quadrant needs no visibility words
+    if ((want_vis || PRIM) && bx < width) {
       const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
 #pragma unroll
       for (int ry = 0; ry < 4; ry++) {
         if (by + ry < height) {
           const size_t o = o0 + (size_t)(ry * width);
-          if (VIS16)  // record indices fit 16 bits (0xFFFF = none): half the visibility traffic
+          if (!want_vis) {
+          } else if (VIS16)  // record indices fit 16 bits (0xFFFF = none): half the visibility traffic
             *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) =
                 make_uint2(__builtin_amdgcn_perm(best_r[ry * 4 + 1], best_r[ry * 4], 0x05040100u),
                            __builtin_amdgcn_perm(best_r[ry * 4 + 3], best_r[ry * 4 + 2], 0x05040100u));
@@ -579,7 +610,8 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
 rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
-                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out, uint32_t *qtab) {
+                           const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out, uint32_t *qtab,
+                           bool skip_described_vis) {
   const uint32_t n = n_poses;
   const uint32_t groups = (n + 7u) / 8u;  // pose groups of eight: one pose per XCD
   if (groups > 65535u || tiles_y > 65535 || (uint64_t)tiles_x * 8ull > 0x7FFFFFFFull)
@@ -590,12 +622,14 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
     HIP_TRY(hipMalloc((void **)&d_stats, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
   }
-  auto pick = [&](auto stats) {
-    constexpr bool S = decltype(stats)::value;
-    return vis16 ? (prim_out ? raster_wave_kernel<S, true, true> : raster_wave_kernel<S, true, false>)
-                 : (prim_out ? raster_wave_kernel<S, false, true> : raster_wave_kernel<S, false, false>);
+  const bool skip = skip_described_vis && qtab != nullptr;  // (without a table every visibility word is needed)
+  auto pick = [&](auto stats, auto skipvis) {
+    constexpr bool S = decltype(stats)::value, K = decltype(skipvis)::value;
+    return vis16 ? (prim_out ? raster_wave_kernel<S, true, true, K> : raster_wave_kernel<S, true, false, K>)
+                 : (prim_out ? raster_wave_kernel<S, false, true, K> : raster_wave_kernel<S, false, false, K>);
   };
-  auto rk = dbg.raster_stats ? pick(std::true_type{}) : pick(std::false_type{});
+  auto rk = dbg.raster_stats ? (skip ? pick(std::true_type{}, std::true_type{}) : pick(std::true_type{}, std::false_type{}))
+                             : (skip ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{}));
   hipLaunchKernelGGL(rk, dim3((uint32_t)tiles_x * 8u, (uint32_t)tiles_y, groups), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, dbg.no_cover ? 1u : 0u,
                      qtab, d_stats);

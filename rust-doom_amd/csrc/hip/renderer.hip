@@ -471,14 +471,17 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   }
   if (marks) HIP_TRY(hipEventRecord(ev[1], st));
   uint32_t *prim_out = b->want_prim ? b->d_prim : nullptr;
+  // one reading of the debug hooks for both kernels: who writes and who reads visibility words must not change in between
+  const FragmentPlan plan = plan_fragment(W, H, b->d_qtab != nullptr);
   if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, W, H, tiles_x, tiles_y,
-                                      b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out, b->d_qtab))
+                                      b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out, b->d_qtab,
+                                      plan.skip_described_vis))
     return rs;
   if (marks) HIP_TRY(hipEventRecord(ev[2], st));
   if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, b->d_poses, W, H, tiles_x,
                                         tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16,
                                         prim_out, b->d_ndc, b->d_fb, b->d_fix_count, b->d_fix_list, b->fix_cap, b->d_qtab, b->d_frag_const,
-                                        &b->frag_const_ready))
+                                        &b->frag_const_ready, plan))
     return rs;
   HIP_TRY(hipGetLastError());
   if (profiled) {

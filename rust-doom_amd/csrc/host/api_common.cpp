@@ -32,7 +32,8 @@ rdoom_status rdoom_debug_set(const char *name, int32_t value) {
   } table[] = {{"no_bins", &o.no_bins},     {"entry_cap", &o.entry_cap},   {"vis32", &o.vis32},
                {"leak_mod", &o.leak_mod},   {"frag_nq", &o.frag_nq},       {"frag_bw", &o.frag_bw},
                {"frag_chunk", &o.frag_chunk}, {"bin_threads", &o.bin_threads}, {"no_cover", &o.no_cover},
-               {"raster_stats", &o.raster_stats}, {"no_qtab", &o.no_qtab}};
+               {"raster_stats", &o.raster_stats}, {"no_qtab", &o.no_qtab},
+               {"keep_vis", &o.keep_vis}};
   for (const auto &t : table)
     if (std::strcmp(t.name, name) == 0) {
       *t.field = value;

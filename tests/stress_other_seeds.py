@@ -62,14 +62,19 @@ def render_mismatches(product, index, lv, n, rng, size):
         poses[i]['projection'], poses[i]['time'] = reference_projection(w, h), t
         lights[i] = lv.lights.fill_buffer_at(t)
     batch = rd.Batch(rd.DeviceLevel(built), w, h, n)
+    # (each checked render follows one of the poses in reverse order: the batch's scratch holds another frame's state)
+    batch.render(poses[::-1].copy(), lights[::-1].copy())
+    batch.render(poses, lights)  # without primitive ids: the path bench.py times
+    fb_plain = batch.read_framebuffer()
     batch.enable_primitive_ids()
+    batch.render(poses[::-1].copy(), lights[::-1].copy())
     batch.render(poses, lights)
     fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
     ro = raster.RasterOracle(lv)
 
     def check(i):
         ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], float(poses[i]['time']), lights[i], w, h, want_prim=True)
-        return int((ofb != fb[i]).sum()), int((oprim != prim[i]).sum())
+        return int((ofb != fb[i]).sum()) + int((ofb != fb_plain[i]).sum()), int((oprim != prim[i]).sum())
 
     with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
         res = list(ex.map(check, range(n)))

@@ -44,7 +44,12 @@ def main():
                 m[1, 3] = 0.0 if (o == 0 or i % 2 == 0) else rng.uniform(-0.8, 0.8)
                 om[i, o] = (v64 @ m).T.astype(np.float32).reshape(16)
         batch = rd.Batch(rd.DeviceLevel(lv), w, h, n)
+        # (each checked render follows one of the poses in reverse order: the batch's scratch holds another frame's state)
+        batch.render(poses[::-1].copy(), lights[::-1].copy(), object_modelviews=om[::-1].copy())
+        batch.render(poses, lights, object_modelviews=om)  # without primitive ids: the path bench.py times
+        fb_plain = batch.read_framebuffer()
         batch.enable_primitive_ids()
+        batch.render(poses[::-1].copy(), lights[::-1].copy(), object_modelviews=om[::-1].copy())
         batch.render(poses, lights, object_modelviews=om)
         fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
         ro = raster.RasterOracle(lv)
@@ -52,7 +57,7 @@ def main():
         def check(i):
             ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], float(poses[i]['time']), lights[i], w, h,
                                    want_prim=True, object_modelviews=om[i])
-            return int((ofb != fb[i]).sum()), int((oprim != prim[i]).sum())
+            return int((ofb != fb[i]).sum()) + int((ofb != fb_plain[i]).sum()), int((oprim != prim[i]).sum())
 
         with ThreadPoolExecutor(os.cpu_count() or 1) as ex:
             res = list(ex.map(check, range(n)))

@@ -79,10 +79,14 @@ def test_fragment_wave_block_shapes(bw):
 
 
 @pytest.mark.parametrize('hooks', [{'no_qtab': 1}, {'frag_bw': 2}, {'frag_bw': 2, 'no_qtab': 1}, {'frag_bw': 3, 'frag_nq': 1},
-                                   {'frag_bw': 4, 'frag_nq': 1}, {'frag_bw': 2, 'no_bins': 1}, {'frag_bw': 3, 'vis32': 1}])
+                                   {'frag_bw': 4, 'frag_nq': 1}, {'frag_bw': 2, 'no_bins': 1}, {'frag_bw': 3, 'vis32': 1},
+                                   {'keep_vis': 1}, {'keep_vis': 1, 'frag_bw': 2}, {'leak_mod': 5}, {'leak_mod': 3, 'frag_bw': 2},
+                                   {'frag_bw': 5}, {'frag_bw': 1}])
 def test_quadrant_table_paths(hooks):
     """the table serves 32-pixel-wide blocks (one quadrant) and 64-pixel-wide ones (two quadrants side by side), with 8- and
-    4-pixel runs per lane; frames whose right / top quadrants are partly outside (1000 x 520 = 15.6 x 8.1 tiles)"""
+    4-pixel runs per lane; frames whose right / top quadrants are partly outside (1000 x 520 = 15.6 x 8.1 tiles).  Where the
+    table is in use the rasteriser leaves out the visibility words of the quadrants it describes (keep_vis: writes them all the
+    same; leak_mod: the fragment kernel wants them all; block shapes the table does not serve, frag_bw 1 / 5: no table at all)"""
     for args in (('0', '320', '200', '6'), ('0', '1000', '520', '3'), ('3', '712', '296', '3')):
         bad, _ = run_child(hooks, args)
         assert bad == 0, (hooks, args)
