@@ -20,8 +20,9 @@ namespace {
 
 // =================================================================================================
 // Kernel 3: fragment kernel (F1..F6): visibility record -> atlas texel -> COLORMAP row -> 8-bit
-// palette index.  One lane per run of 8 (or 4) horizontally adjacent pixels: one 16-byte visibility
-// load, one 8-byte packed store; a wavefront takes a block of 8 runs x 8 rows per iteration (64 x 8 pixels: its
+// palette index.  One lane per run of 8 (or 4) horizontally adjacent pixels: the record from the rasteriser's
+// quadrant table where it has an entry (no visibility words exist there), else one 16-byte visibility
+// load; one 8-byte packed store; a wavefront takes a block of 8 runs x 8 rows per iteration (64 x 8 pixels: its
 // texel gathers and record loads then fall into a compact patch).  COLORMAP (8 KiB) is staged in LDS once per
 // workgroup, whose four waves walk FRAG_CHUNK such blocks each (all workgroups of a pose run on one XCD).
 //
@@ -233,6 +234,9 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
     // ONE record, the block's visibility words are neither loaded nor compared (all scalar: the block origin is uniform).
     // qtab_mode 1: the block is 32 pixels wide (inside one quadrant); 2: 64 pixels wide (two quadrants of one tile, side
     // by side -- the right one may lie outside the frame, where the rasteriser writes nothing).
+    // A quadrant with an entry HAS no visibility words (the rasteriser leaves them out, raster.hip SKIPVIS): wherever an
+    // entry exists it is the only source.  Two quadrants with different entries, or one with and one without: each lane takes
+    // its own quadrant's entry (tl), and only lanes without one load visibility words.
     uint32_t tq = NONE;
     uint32_t tl = NONE;  // per lane: the entry of the quadrant my pixels lie in, when the block spans two that differ
     if (qtab_mode != 0u) {

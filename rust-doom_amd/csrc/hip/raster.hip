@@ -574,6 +574,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       if (rf != NONE && __all(outside_lane | ((lo == rf) & (hi == rf)))) described = rf;
     }
 #endif
+    if (STATS && described != NONE) st[11]++;
     if (qtab && lane == 0) qtab[((size_t)pose * T + tile) * 4u + (uint32_t)q] = described;  // NONE: not known to be uniform
     const bool want_vis = !SKIPVIS || described == NONE;  // (uniform) a described quadrant needs no visibility words
     if ((want_vis || PRIM) && bx < width) {
@@ -640,10 +641,10 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
     const double waves = (double)groups * 8.0 * (double)(tiles_x * tiles_y) * 4.0;  // (pose, quadrant) passes
     fprintf(stderr,
             "[rdoom stats] per quadrant pass: queue %.1f  past quadrant early-z %.1f  quadrant-cover %.2f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
-            "  general %.3f (lanes %.1f: masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | one-entry shortcut %.3f\n",
+            "  general %.3f (lanes %.1f: masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | one-entry shortcut %.3f, one winner in the end %.3f\n",
             h[0] / waves, h[1] / waves, h[10] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
             h[4] ? (double)h[5] / h[4] : 0.0, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
-            h[6] ? (double)h[12] / h[6] : 0.0, h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, h[9] / waves);
+            h[6] ? (double)h[12] / h[6] : 0.0, h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, h[9] / waves, h[11] / waves);
   }
   return RDOOM_OK;
 }

@@ -9,7 +9,11 @@ process sets its own, they are process-wide).  Every hook selects an equivalent 
   no_cover=1     the rasteriser without its depth-only body for quadrant-covering triangles;
   frag_bw=k      the fragment kernel's wave block is 2^k units wide (default 3: 64 x 8 pixels);
   no_qtab=1      the fragment kernel ignores the rasteriser's quadrant table ("every pixel of this 32 x 32 quadrant shows
-                 record r") and reads the visibility words of every block, as it did before the table existed."""
+                 record r") and reads the visibility words of every block, as it did before the table existed;
+  keep_vis=1     the rasteriser writes the visibility words of every quadrant, also of those its table describes (by default it
+                 leaves them out and every reader asks the table first).
+Each child renders another set of poses into its batch before the checked render: whatever the checked render does not write
+holds another frame's values.  The image is checked with and without primitive ids."""
 import os
 import re
 import subprocess
