@@ -354,8 +354,16 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
           const float n1 = fmaf(e1a, pos(e1a) ? xl : xh, fmaf(e1b, pos(e1b) ? yl : yh, e1c));
           const float n2 = fmaf(e2a, pos(e2a) ? xl : xh, fmaf(e2b, pos(e2b) ? yl : yh, e2c));
           const float rwn = fmaf(wa, pos(wa) ? xl : xh, fmaf(wb, pos(wb) ? yl : yh, wc));
+          // (the bbox is clipped to the frame: a quadrant that crosses the frame's right or bottom edge is covered when the
+          // bbox reaches that edge -- the pixels beyond it do not exist; the corner values above are those of the whole
+          // quadrant, which only asks for more)
+#ifndef RDOOM_NO_EDGE_COVER
+          const int qx1 = min(rx0 + 31, width - 1), qy1 = min(ry0 + 31, height - 1);
+#else
+          const int qx1 = rx0 + 31, qy1 = ry0 + 31;
+#endif
           const bool cov = (n0 > 0.0f) & (n1 > 0.0f) & (n2 > 0.0f) & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) &
-                           (x0 <= rx0) & (x1 >= rx0 + 31) & (y0 <= ry0) & (y1 >= ry0 + 31) &
+                           (x0 <= rx0) & (x1 >= qx1) & (y0 <= ry0) & (y1 >= qy1) &
                            ((c4.y & RASTER_MASKED_INTERIOR) == 0u);
           myqb |= (cov && !no_cover) ? (16u << qi) : 0u;  // no_cover: test hook
         }
@@ -373,8 +381,9 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
 #ifndef RDOOM_NO_TILE_SHORTCUT
   // The same shortcut one level up: the tile's nearest entry (lane 0: the list is ranked) covers all four quadrants and
   // every other entry lies, in every quadrant it touches, strictly behind that entry's farthest depth over the whole tile.
-  // (A tile that crosses the frame's edge never qualifies: cover needs the bbox, which is clipped to the frame.)
-  if (single && n != 0u) {
+  // (Whole tiles only: its stores carry no frame checks.  The quadrants of a tile that crosses the frame's edge take the
+  // quadrant-level shortcut below.)
+  if (single && n != 0u && tx0 + TILE_W <= width && ty0 + TILE_H <= height) {
     const uint32_t rq0 = (uint32_t)__builtin_amdgcn_readlane((int)myrq, 0);
     if ((rq0 >> 28) == 0xFu) {
       const float za0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpa, 0)),
