@@ -38,9 +38,20 @@ def driver():
     srcs = sorted(glob.glob(os.path.join(host, '*.cpp'))) + [os.path.join(HERE, 'sanitize', 'host_driver.cpp')]
     deps = srcs + glob.glob(os.path.join(host, '*.hpp')) + [os.path.join(ROOT, 'include', 'rdoom.h'),
                                                             os.path.join(ROOT, 'rust-doom_amd', 'csrc', 'common.hpp')]
+    os.makedirs(BUILD, exist_ok=True)
+    import fcntl
+    lock = open(os.path.join(BUILD, '.lock'), 'w')  # (pytest-xdist: one worker builds, the others wait and find it built)
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        return _build_driver(host, srcs, deps)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_driver(host, srcs, deps):
     if os.path.exists(DRIVER) and all(os.path.getmtime(d) <= os.path.getmtime(DRIVER) for d in deps):
         return DRIVER
-    os.makedirs(BUILD, exist_ok=True)
     flags = ['-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-ffp-contract=off',
              '-I' + os.path.join(ROOT, 'include'), '-I' + host, '-I' + os.path.join(ROOT, 'rust-doom_amd', 'csrc')]
 
