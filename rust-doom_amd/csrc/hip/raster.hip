@@ -231,6 +231,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return max(max(a, b), max(c, d));
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {  // (the same reduction with min)
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x141, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x140, 0xF, 0xF, false));
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                 c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(a, b), min(c, d));
+}
+
 #ifndef RDOOM_RASTER_OCC
 #define RDOOM_RASTER_OCC 4  // waves per SIMD the register allocation aims at (128 VGPRs)
 #endif
@@ -379,23 +389,29 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   if (single && count != 0u) gather(0u);
 #endif
 #ifndef RDOOM_NO_TILE_SHORTCUT
-  // The same shortcut one level up: the tile's nearest entry (lane 0: the list is ranked) covers all four quadrants and
-  // every other entry lies, in every quadrant it touches, strictly behind that entry's farthest depth over the whole tile.
+  // The same shortcut one level up: the tile's nearest entry (by its nearest depth over the quadrants it touches, not by its
+  // place in the ranked list) covers all four quadrants and every other entry lies, in every quadrant it touches, strictly
+  // behind that entry's farthest depth over the whole tile.
   // (Whole tiles only: its stores carry no frame checks.  The quadrants of a tile that crosses the frame's edge take the
   // quadrant-level shortcut below.)
   if (single && n != 0u && tx0 + TILE_W <= width && ty0 + TILE_H <= height) {
-    const uint32_t rq0 = (uint32_t)__builtin_amdgcn_readlane((int)myrq, 0);
+    // my entry's nearest depth over the quadrants it touches (lanes without an entry hold NONE everywhere)
+    const uint32_t tq = myrq >> 24;
+    const uint32_t near_all = min(min((tq & 1u) ? dnq0 : NONE, (tq & 2u) ? dnq1 : NONE), min((tq & 4u) ? dnq2 : NONE, (tq & 8u) ? dnq3 : NONE));
+#ifndef RDOOM_RANKED_SHORTCUT
+    const uint32_t sc = (uint32_t)__builtin_ctzll(__ballot(near_all == wave_min_u32(near_all)));  // the nearest entry of the tile
+#else
+    const uint32_t sc = 0u;  // the first of the ranked list
+#endif
+    const uint32_t rq0 = (uint32_t)__builtin_amdgcn_readlane((int)myrq, (int)sc);
     if ((rq0 >> 28) == 0xFu) {
-      const float za0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpa, 0)),
-                  zb0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpb, 0)),
-                  zc0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpc, 0));
+      const float za0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpa, (int)sc)),
+                  zb0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpb, (int)sc)),
+                  zc0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpc, (int)sc));
       const float xl = (float)tx0 + 0.5f, xh = (float)tx0 + 63.5f, yl = (float)ty0 + 0.5f, yh = (float)ty0 + 63.5f;
       const float zf0 = fmaf(za0, pos(za0) ? xh : xl, fmaf(zb0, pos(zb0) ? yh : yl, zc0));  // in [0, 1]: the entry covers
       const uint32_t df0 = __float2uint_rz(fmaf(zf0, 16777215.0f, 0.5f));
-      // my entry's nearest depth over the quadrants it touches (lanes without an entry hold NONE everywhere)
-      const uint32_t tq = myrq >> 24;
-      const uint32_t near_all = min(min((tq & 1u) ? dnq0 : NONE, (tq & 2u) ? dnq1 : NONE), min((tq & 4u) ? dnq2 : NONE, (tq & 8u) ? dnq3 : NONE));
-      if ((__ballot(near_all <= df0) & ~1ull) == 0ull) {
+      if ((__ballot(near_all <= df0) & ~(1ull << sc)) == 0ull) {
         const uint32_t r0 = rq0 & 0xFFFFFFu;
         const uint32_t p0 = PRIM ? (prec[r0].r.flags & 0xFFFFFFu) : 0u;
         if (STATS) st[0] += (unsigned long long)n, st[9] += 4ull;
@@ -440,7 +456,14 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       const unsigned long long touch_s = __ballot(((myrq >> (24 + q)) & 1u) != 0u);
       const unsigned long long cover_s = __ballot(((myrq >> (28 + q)) & 1u) != 0u);
       if (touch_s != 0ull) {
+#ifndef RDOOM_RANKED_SHORTCUT
+        // the entry with the nearest depth over THIS quadrant, wherever it stands in the tile's ranking (the ranking is by
+        // the triangles' depth as a whole: a floor triangle that starts at the camera's feet precedes the wall it ends at)
+        const uint32_t near_q = wave_min_u32(((myrq >> (24 + q)) & 1u) ? dnq_s : NONE);
+        const uint32_t s0 = (uint32_t)__builtin_ctzll(__ballot(dnq_s == near_q) & touch_s);
+#else
         const uint32_t s0 = (uint32_t)__builtin_ctzll(touch_s);
+#endif
         if ((cover_s >> s0) & 1ull) {
           const float za0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpa, (int)s0)),
                       zb0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpb, (int)s0)),
