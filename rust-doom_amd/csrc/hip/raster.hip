@@ -524,9 +524,22 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       uint32_t wave_far = wave_max_u32(lane_far);
       unsigned long long wm = touch & __ballot(dnq <= wave_far);
       if (STATS) st[0] += (unsigned long long)__popcll(touch), st[15] += (unsigned long long)__popcll(touch & ~wm);
+#ifndef RDOOM_RANKED_WALK
+      // The covering entry that is nearest over this quadrant goes first, wherever it stands in the ranking (the winner does
+      // not depend on the order): its depth-only body then puts a bound on every lane, and entries ranked before it that lie
+      // behind it are dropped by the compare below instead of being rasterised.
+      uint32_t s_first = 64u;
+      if (qcm & wm) s_first = (uint32_t)__builtin_ctzll(__ballot(dnq == wave_min_u32(((qcm >> lane) & 1ull) ? dnq : NONE)) & qcm & wm);
+#endif
       while (wm) {
+#ifndef RDOOM_RANKED_WALK
+        const uint32_t s = s_first < 64u ? s_first : (uint32_t)__builtin_ctzll(wm);
+        s_first = 64u;
+        wm &= ~(1ull << s);
+#else
         const uint32_t s = (uint32_t)__builtin_ctzll(wm);
         wm &= wm - 1ull;
+#endif
         const uint32_t far_before = lane_far;
         auto refresh = [&]() {  // after a body: drop what is hidden now
           if (__any(lane_far != far_before)) {
