@@ -18,6 +18,25 @@
 namespace rdoom_dev {
 namespace {
 
+// Section timers (tools/variant.sh NAME raster -DRDOOM_RASTER_TIMERS; never in the shipped library): where does a wave's
+// time go?  Every mark waits for the wave's outstanding memory operations, reads the shader clock (s_memtime) and
+// charges the cycles since the previous mark to a section; lane 0 adds the wave's sums to g_raster_t at the end.  The
+// waits serialise what would overlap and the reads cost cycles themselves: the SHARES are the result, not the total.
+#ifdef RDOOM_RASTER_TIMERS
+__device__ unsigned long long g_raster_t[16];
+__device__ __forceinline__ unsigned long long rt_now() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  return __builtin_readcyclecounter();
+}
+#define RT_DECL uint32_t rt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long rt_last = rt_now();
+#define RT_MARK(i) do { const unsigned long long n_ = rt_now(); rt_acc[i] += (uint32_t)(n_ - rt_last); rt_last = n_; } while (0)
+#define RT_FLUSH() do { if (lane == 0) { for (int k_ = 0; k_ < 10; k_++) atomicAdd(&g_raster_t[k_], (unsigned long long)rt_acc[k_]); atomicAdd(&g_raster_t[15], 1ull); } } while (0)
+#else
+#define RT_DECL
+#define RT_MARK(i) do { } while (0)
+#define RT_FLUSH() do { } while (0)
+#endif
+
 // =================================================================================================
 // Rasteriser, per-entry part.  Rejection is hierarchical and exact: fmaf is monotone in each argument, so the
 // extreme of a *computed* edge function, depth plane or 1/w plane over a pixel rectangle sits at a corner --
@@ -278,6 +297,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   const int tid = threadIdx.x, wave = 0, lane = tid & 63;
   const uint32_t tile_x = blockIdx.x >> 3, tile_y = blockIdx.y, tile = tile_y * (uint32_t)tiles_x + tile_x;
   if (pose >= n_poses) return;
+  RT_DECL
   const int tx0 = (int)tile_x * TILE_W, ty0 = (int)tile_y * TILE_H;
   const int lx = (lane & 7) * 4, ly = (lane >> 3) * 4;  // this lane's 4x4 block inside a quadrant
   const TriRec *prec = recs + (size_t)pose * cap;
@@ -383,7 +403,12 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   };
+#ifdef RDOOM_RASTER_TIMERS
+  asm volatile("" ::"s"(count));
+#endif
+  RT_MARK(0);  // header, overflow flag, count
   if (single && count != 0u) gather(0u);
+  RT_MARK(1);  // list gather: entries, ranking, records, per-quadrant nearest depths and cover flags
 #ifdef RDOOM_TIMING_EXPERIMENTS  // the list gather and record set-up run twice: the difference in kernel time is their cost
   asm volatile("" ::: "memory");
   if (single && count != 0u) gather(0u);
@@ -436,11 +461,14 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
         }
         if (STATS && lane == 0)
           for (int k = 0; k < 16; k++) atomicAdd(&stats[k], st[k]);
+        RT_MARK(2);  // tile-level shortcut, taken
+        RT_FLUSH();
         return;
       }
     }
   }
 #endif
+  RT_MARK(3);  // tile-level shortcut, not taken
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
     const int qx0 = tx0 + (q & 1) * 32, qy0 = ty0 + (q >> 1) * 32;  // this quadrant
@@ -494,11 +522,13 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
                 }
               }
             }
+            RT_MARK(4);  // quadrant shortcut, taken
             continue;
           }
         }
       }
     }
+    RT_MARK(5);  // quadrant shortcut, not taken
     uint32_t best_d[16], best_r[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -531,6 +561,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       uint32_t s_first = 64u;
       if (qcm & wm) s_first = (uint32_t)__builtin_ctzll(__ballot(dnq == wave_min_u32(((qcm >> lane) & 1ull) ? dnq : NONE)) & qcm & wm);
 #endif
+      RT_MARK(6);  // quadrant pass set-up: initialisation, wave-wide farthest depth, first covering entry
       while (wm) {
 #ifndef RDOOM_RANKED_WALK
         const uint32_t s = s_first < 64u ? s_first : (uint32_t)__builtin_ctzll(wm);
@@ -584,6 +615,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
           }
           if (!__any(tiez == 0u)) {
             refresh();
+            RT_MARK(7);  // covering entry: depth-only body
             continue;
           }
         }
@@ -598,6 +630,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
                                  uf(r3.x), za, zb, zc, uf(r2.x), uf(r2.y), uf(r2.z), x0, y0, x1, y1, flags, ridx, bx, by, pxlo,
                                  pxhi, pylo, pyhi, best_d, best_r, lane_far, [&]() -> ShadeRec { return prec[ridx].s; }, st);
         refresh();
+        RT_MARK(8);  // other entry: record broadcast, rejection tests, pixel bodies
       }
     }
     // ---- this quadrant's visibility words ------------------------------------------------------------------------
@@ -646,7 +679,9 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
         }
       }
     }
+    RT_MARK(9);  // one-winner check, table entry, visibility words
   }
+  RT_FLUSH();
   if (STATS && lane == 0)
     for (int k = 0; k < 16; k++) atomicAdd(&stats[k], st[k]);
 }
@@ -679,6 +714,21 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
   hipLaunchKernelGGL(rk, dim3((uint32_t)tiles_x * 8u, (uint32_t)tiles_y, groups), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, dbg.no_cover ? 1u : 0u,
                      qtab, d_stats);
+#ifdef RDOOM_RASTER_TIMERS
+  {
+    unsigned long long h[16], zero[16] = {};
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_raster_t), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raster_t), zero, sizeof zero);
+    unsigned long long total = 0;
+    for (int k = 0; k < 10; k++) total += h[k];
+    static const char *names[10] = {"header", "gather", "tile shortcut taken", "tile shortcut not taken", "quadrant shortcut taken",
+                                    "quadrant shortcut not taken", "pass set-up", "cover body", "other entry", "final check + stores"};
+    fprintf(stderr, "[raster timers] %llu waves, %.0f cycles per wave:", h[15], h[15] ? (double)total / (double)h[15] : 0.0);
+    for (int k = 0; k < 10; k++) fprintf(stderr, "  %s %.1f %%", names[k], total ? 100.0 * (double)h[k] / (double)total : 0.0);
+    fprintf(stderr, "\n");
+  }
+#endif
   if (d_stats) {
     unsigned long long h[16];
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
