@@ -22,6 +22,7 @@ struct DebugOptions {
   int bin_threads = 256; // workgroup size of the binning kernel
   int no_cover = 0;      // no depth-only body for quadrant-covering triangles
   int no_qtab = 0;       // the fragment kernel ignores the rasteriser's quadrant table (every wave reads its visibility words)
+  int qpath = 0;         // the whole-quadrant fragment kernel runs first (off by default: measured slower)
   int keep_vis = 0;      // the rasteriser writes the visibility words of every quadrant, also of those the table describes
   int raster_stats = 0;  // census of the rasteriser's paths on stderr (instrumented instantiation: slower)
 };

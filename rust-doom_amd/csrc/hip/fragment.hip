@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
       // words for that quadrant), else the pixel's visibility word
       uint32_t id = NONE;
       if (qtab_mode != 0u)
-        id = qtab[((size_t)pose * n_tiles + ((row >> 6) * tiles_x + (qx >> 4))) * 4u + ((row >> 5) & 1u) * 2u + ((qx >> 3) & 1u)];
+        id = qtab_record(qtab[((size_t)pose * n_tiles + ((row >> 6) * tiles_x + (qx >> 4))) * 4u + ((row >> 5) & 1u) * 2u + ((qx >> 3) & 1u)]);
       if (id == NONE) id = VIS16 ? (uint32_t)pvis16[(size_t)qi * 4u + k] : pvis32[(size_t)qi * 4u + k];
       uint32_t c = 0;
       const uint32_t pix = (row * quads_per_row + qx) * 4u + k;
@@ -242,14 +242,31 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
     if (qtab_mode != 0u) {
       const uint32_t bx0 = (wbx << bw_log2) * (uint32_t)NPX, by0 = wby << (6u - bw_log2);
       const uint32_t *e = qtab + ((size_t)pose * n_tiles + ((by0 >> 6) * tiles_x + (bx0 >> 6))) * 4u + ((by0 >> 5) & 1u) * 2u;
+      // A quadrant fragment_quadrant_kernel has shaded carries QTAB_HANDLED: a block that lies in handled quadrants only is
+      // done (wave-uniform: the entries arrive by scalar loads).  A block with one handled half shades that half again from
+      // the entry like any other described quadrant -- same record, same operations, same bytes.
       if (qtab_mode == 1u) {
-        tq = e[(bx0 >> 5) & 1u];
+        const uint32_t one = e[(bx0 >> 5) & 1u];
+#ifdef RDOOM_FRAG_STATS
+        if (lane == 0u) atomicAdd(&g_frag_stats[qtab_handled(one) ? 1 : 0], 1ull);
+#endif
+        if (qtab_handled(one)) continue;
+        tq = one;
       } else {
         const uint2 two = *reinterpret_cast<const uint2 *>(e);
-        const bool same = two.x == two.y || bx0 + 32u >= (uint32_t)width;
-        tq = same ? two.x : NONE;
+        const bool right_out = bx0 + 32u >= (uint32_t)width;
+#ifdef RDOOM_FRAG_STATS
+        if (lane == 0u) {
+          atomicAdd(&g_frag_stats[(qtab_handled(two.x) & (right_out | qtab_handled(two.y))) ? 1 : 0], 1ull);
+          if (qtab_handled(two.x) != (right_out | qtab_handled(two.y))) atomicAdd(&g_frag_stats[2], 1ull);
+        }
+#endif
+        if (qtab_handled(two.x) & (right_out | qtab_handled(two.y))) continue;
+        const uint32_t left = qtab_record(two.x), right = qtab_record(two.y);
+        const bool same = left == right || right_out;
+        tq = same ? left : NONE;
 #ifndef RDOOM_FRAG_NO_TL  // (A/B builds only: without the per-lane entries every visibility word must be there -- keep_vis)
-        tl = same ? NONE : (((lane_col * (uint32_t)NPX) & 32u) ? two.y : two.x);
+        tl = same ? NONE : (((lane_col * (uint32_t)NPX) & 32u) ? right : left);
 #endif
       }
     }
@@ -530,6 +547,280 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
 }
 
 // =================================================================================================
+// Kernel 3a: the whole-quadrant path.  73 % of the 32 x 32 quadrants of a 1080p sweep show ONE triangle and the rasteriser's
+// quadrant table says which (raster.hip).  fragment_kernel's block loop spends more issue cycles AROUND the pixel arithmetic
+// of such a block (block index -> position, table look-up, record loads, range / mod / opacity guards, visibility
+// bookkeeping, COLORMAP rows at both ends of every run) than in it -- tools/isa_blocks.py: about 1 250 VALU cycles per
+// 8-pixel run of which 560 are the four pixel pairs.  Here a wavefront takes a 64 x 64 tile, reads the tile's four table
+// entries with one scalar load and shades every described quadrant whose record is SHADE_FAST as two half quadrants of
+// 32 x 16 pixels, lane per 8-pixel run:
+//   * the record arrives once per quadrant by scalar loads and everything that depends only on it is computed once:
+//     reciprocal tile sizes, the texel-store window, masks, the scaled atlas origin; the body is instantiated per record
+//     class (power-of-two sizes or certified integer mod; byte texel loads or 16-bit ones with the opacity test);
+//   * 1/w is evaluated at the quadrant's four corner pixels: fmaf is monotone in each argument, so when the corners lie in
+//     [2^-100, 2^100] every pixel's computed 1/w lies in the range where exact_rcp2 equals the division bit for bit (a
+//     quadrant that fails is left to fragment_kernel);
+//   * COLORMAP rows once per quadrant instead of twice per run: lane l evaluates F4 / F5 at one end of screen row l / 2 of the
+//     quadrant; 1/w is monotone along a row, so equal rows at the two ends are the row of all 32 pixels between them; a lane
+//     picks its row's value up with one ds_bpermute.  Only when some row's ends disagree do the runs evaluate their own ends
+//     (and the pixels between them when those disagree), as fragment_kernel does;
+//   * the texel's byte offset comes from two and-s and an or: the atlas origin is added with fma(r, 2, 2 atlas_u) =
+//     2 RN(r + atlas_u) and fma(r, 2 W, 2 W atlas_v) = 2 W RN(r + atlas_v) (scaling by a power of two commutes with the
+//     rounding), floor of those is 2 floor(x) + {0, 1} and 2 W floor(y) + {0 .. 2 W - 1}, and the masks (W - 1) << 1 and
+//     (H - 1) << (log2 W + 1) drop exactly the surplus bits (coordinates are >= 0: a mod result plus an atlas position);
+//   * what fragment_kernel sends to its general per-pixel body -- a run whose integer mod is not certified, a transparent
+//     texel under a winner the rasteriser treated as opaque -- is queued for fixup_kernel here, pixel by pixel: the general
+//     rule R1..R6 + plain IEEE division, same bytes (a handful of pixels per batch).
+// Same operations on the same operands as fragment_kernel's packed body (F1..F6), hence the same bits.  A quadrant shaded
+// here gets QTAB_HANDLED in its table entry; fragment_kernel, launched next on the same stream, skips the blocks whose
+// quadrants are handled and treats every other entry as before.
+// =================================================================================================
+#ifndef RDOOM_QUAD_TILES
+#define RDOOM_QUAD_TILES 4
+#endif
+#ifndef RDOOM_QUAD_NP2
+#define RDOOM_QUAD_NP2 1  // 0: quadrants whose record has a non-power-of-two tile size are left to fragment_kernel (two instantiations of the body fewer: 64 VGPRs)
+#endif
+#ifndef RDOOM_QUAD_OCC
+#define RDOOM_QUAD_OCC 5  // waves per SIMD the register allocation must allow (96 VGPRs; 8 with RDOOM_QUAD_NP2 = 0: measured alike)
+#endif
+#define QUAD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RDOOM_QUAD_OCC, 8)))
+constexpr uint32_t QUAD_TILES_PER_WAVE = RDOOM_QUAD_TILES;  // a workgroup = 4 waves x this many tiles shares one LDS copy of COLORMAP
+
+__device__ __forceinline__ f32x2 colormap_rows(f32x2 dist, float light2) {  // F4, F5 for two pixels
+  const f32x2 dterm = splat(1.0f) - exact_div09_2(dist + splat(0.9f));
+  const f32x2 lgt = splat(light2) - f32x2{fminf(1.0f, dterm.x), fminf(1.0f, dterm.y)};
+  const f32x2 tt = (splat(1.0f) - lgt) * splat(32.0f);
+  return f32x2{fminf(fmaxf(floorf(tt.x), 0.0f), 31.0f), fminf(fmaxf(floorf(tt.y), 0.0f), 31.0f)};
+}
+__device__ __forceinline__ float colormap_row(float dist, float light2) {  // the same operations for one pixel
+  const float dterm = 1.0f - exact_div09(dist + 0.9f);
+  const float lgt = light2 - fminf(1.0f, dterm);
+  const float tt = (1.0f - lgt) * 32.0f;
+  return fminf(fmaxf(floorf(tt), 0.0f), 31.0f);
+}
+
+__device__ __forceinline__ void queue_fixup(const FragConst *fc, uint32_t pose, uint32_t pix) {
+  const uint32_t slot = atomicAdd(fc->fix_count, 1u);
+  if (slot < fc->fix_cap) fc->fix_list[slot] = make_uint2(pose, pix);  // (beyond the capacity: fixup_kernel raises the error flag)
+}
+
+// One described quadrant, two half quadrants of 32 x 16 pixels.  NP2: a tile size is an integer that is not a power of two
+// (reciprocal by exact_rcp2, the floor certified per run as in fragment_kernel); MASKED: the texture has transparent texels
+// in its rectangle or the ring around it (16-bit texel loads and the opacity test; otherwise the low byte alone is loaded).
+template <bool NP2, bool MASKED>
+__device__ __forceinline__ void shade_quadrant(const FragConst *__restrict__ fc, const uint8_t *cmap, const char *tb, char *pfb, uint32_t pose,
+                                               const uint4 r0, const uint4 r1, const uint4 r2, const uint4 r3, uint32_t qx0, uint32_t qy0,
+                                               uint32_t lane, int width, int height) {
+  const uint32_t flags = r3.z, tex = r3.w;
+  const float wa = __uint_as_float(r0.x), wb = __uint_as_float(r0.y), wc = __uint_as_float(r0.z),
+              ua = __uint_as_float(r0.w), ub = __uint_as_float(r1.x), uc = __uint_as_float(r1.y),
+              va = __uint_as_float(r1.z), vb = __uint_as_float(r1.w), vc = __uint_as_float(r2.x),
+              atlas_u = __uint_as_float(r2.y), atlas_v = __uint_as_float(r2.z), size_x = __uint_as_float(r2.w),
+              size_y = __uint_as_float(r3.x), light = __uint_as_float(r3.y);
+  // per record: reciprocal tile sizes (an exponent flip for a power of two), texel-store window, scaled origin
+  f32x2 inv_s = {__uint_as_float(0x7F000000u - __float_as_uint(size_x)), __uint_as_float(0x7F000000u - __float_as_uint(size_y))};
+  if (NP2) inv_s = exact_rcp2(f32x2{size_x, size_y});
+  const bool p2x = (flags & SHADE_POW2_X) != 0u, p2y = (flags & SHADE_POW2_Y) != 0u;
+  const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u;
+  const uint32_t wm2 = wm << 1, hms = hm << (lw + 1u);
+  const char *tbase = tb + (size_t)((flags >> 16) << 11);  // (texel base >> 10) << 10 texels of two bytes
+  const float ys = __uint_as_float((128u + lw) << 23);      // 2 W = 2^(lw + 1)
+  const float au2 = atlas_u * 2.0f, avs = atlas_v * ys, light2 = light * 2.0f;
+  const uint32_t lc8 = (lane & 3u) * 8u, lr = lane >> 2;  // my run inside a half quadrant: column of 8 pixels, row
+  const float px0 = (float)(qx0 + lc8) + 0.5f;
+  const bool xin = qx0 + lc8 < (uint32_t)width;
+  // COLORMAP row of every screen row of the quadrant, from its two end pixels: lane l -> row l / 2, end l & 1
+  uint32_t row_word;  // row << 8, bit 31 = the two ends disagree
+  {
+    const float pye = (float)(qy0 + (lane >> 1)) + 0.5f, pxe = (float)(qx0 + (lane & 1u) * 31u) + 0.5f;
+    const float re = colormap_row(exact_rcp(fmaf(wa, pxe, fmaf(wb, pye, wc))), light2);
+    const float ro = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(re), 0xB1, 0xF, 0xF, true));  // quad_perm [1, 0, 3, 2]
+    row_word = ((uint32_t)(int)re << 8) | (re == ro ? 0u : 0x80000000u);
+  }
+#pragma unroll 1
+  for (uint32_t h = 0; h < 2u; h++) {
+    const uint32_t y = qy0 + h * 16u + lr;
+    const float py = (float)y + 0.5f;
+    const float row_w = fmaf(wb, py, wc), row_u = fmaf(ub, py, uc), row_v = fmaf(vb, py, vc);
+    const uint32_t my_row = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((h * 16u + lr) * 8u), (int)row_word);  // from lane 2 (h 16 + lr)
+    // NP2: one guard per run and axis, exactly as in fragment_kernel (see there for the argument)
+    bool mod_ok = true;
+    float lox = 0.0f, hix = 0.0f, loy = 0.0f, hiy = 0.0f;
+    if (NP2) {
+      const float pxl = px0 + 7.0f;
+      const f32x2 w_ends = exact_rcp2(f32x2{fmaf(wa, px0, row_w), fmaf(wa, pxl, row_w)});
+      const float w_hi = fmaxf(w_ends.x, w_ends.y);
+      const float bu = fmaxf(fabsf(fmaf(ua, px0, row_u)), fabsf(fmaf(ua, pxl, row_u))) * w_hi;
+      const float bv = fmaxf(fabsf(fmaf(va, px0, row_v)), fabsf(fmaf(va, pxl, row_v))) * w_hi;
+      lox = fmaxf(bu, size_x) * 0x1p-20f, hix = size_x - lox;
+      loy = fmaxf(bv, size_y) * 0x1p-20f, hiy = size_y - loy;
+      mod_ok = (p2x | (bu < 0x1p23f)) & (p2y | (bv < 0x1p23f));
+    }
+    uint32_t texel[8], any_texel = 0;
+    float w_first = 0.0f, w_last = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const f32x2 px = {px0 + (float)(2 * p), px0 + (float)(2 * p + 1)};
+      const f32x2 w = exact_rcp2(pk_fma(splat(wa), px, splat(row_w)));  // F1
+      if (p == 0) w_first = w.x;
+      if (p == 3) w_last = w.y;
+      const f32x2 tu = pk_fma(splat(ua), px, splat(row_u)) * w;
+      const f32x2 tv = pk_fma(splat(va), px, splat(row_v)) * w;
+      f32x2 fq = tu * splat(inv_s.x);  // F2: mod(t, size) = t - size * floor(t / size)
+      fq = f32x2{floorf(fq.x), floorf(fq.y)};
+      const f32x2 rx = pk_fma(splat(-size_x), fq, tu);
+      f32x2 fh = tv * splat(inv_s.y);
+      fh = f32x2{floorf(fh.x), floorf(fh.y)};
+      const f32x2 ry = pk_fma(splat(-size_y), fh, tv);
+      if (NP2)
+        mod_ok = mod_ok & (p2x | ((rx.x >= lox) & (rx.x <= hix) & (rx.y >= lox) & (rx.y <= hix))) &
+                 (p2y | ((ry.x >= loy) & (ry.x <= hiy) & (ry.y >= loy) & (ry.y <= hiy)));
+      const f32x2 ux2 = pk_fma(rx, splat(2.0f), splat(au2));  // F3: 2 (r + atlas_u), 2 W (r + atlas_v), rounded as the sums round
+      const f32x2 uys = pk_fma(ry, splat(ys), splat(avs));
+      const uint32_t b0 = ((uint32_t)cvt_floor_i32(uys.x) & hms) | ((uint32_t)cvt_floor_i32(ux2.x) & wm2);
+      const uint32_t b1 = ((uint32_t)cvt_floor_i32(uys.y) & hms) | ((uint32_t)cvt_floor_i32(ux2.y) & wm2);
+#if defined(RDOOM_TIMING_EXPERIMENTS) && defined(RDOOM_Q_FOLD)  // wrong images by design: what do the gathers cost?
+      texel[2 * p] = RDOOM_Q_FOLD ? *reinterpret_cast<const uint8_t *>(tbase + (b0 & 0x1FEu)) : (b0 & 0xFFu);
+      texel[2 * p + 1] = RDOOM_Q_FOLD ? *reinterpret_cast<const uint8_t *>(tbase + (b1 & 0x1FEu)) : (b1 & 0xFFu);
+#else
+#ifdef RDOOM_Q_LOAD32  // (A/B: 32-bit loads at the texel's 2-byte-aligned address, as fragment_kernel issues them)
+      if (true) {
+        texel[2 * p] = *reinterpret_cast<const TexelWord *>(tbase + b0) & 0xFFFFu;
+        texel[2 * p + 1] = *reinterpret_cast<const TexelWord *>(tbase + b1) & 0xFFFFu;
+      } else
+#endif
+      if (MASKED) {
+        texel[2 * p] = *reinterpret_cast<const uint16_t *>(tbase + b0);
+        texel[2 * p + 1] = *reinterpret_cast<const uint16_t *>(tbase + b1);
+      } else {  // little endian: the palette index is the low byte
+        texel[2 * p] = *reinterpret_cast<const uint8_t *>(tbase + b0);
+        texel[2 * p + 1] = *reinterpret_cast<const uint8_t *>(tbase + b1);
+      }
+#endif
+    }
+    if (MASKED) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) any_texel |= texel[k];
+    }
+    uint32_t ci[8];  // COLORMAP index = row * 256 + texel
+    if (__all((int)my_row >= 0)) {  // (wave-uniform) every screen row of this half quadrant has one COLORMAP row
+#pragma unroll
+      for (int k = 0; k < 8; k++) ci[k] = MASKED ? (my_row | (texel[k] & 0xFFu)) : (my_row | texel[k]);
+    } else {
+      // F4, F5 at the run's two end pixels; the pixels between them only when the ends disagree
+      const f32x2 rf_ends = colormap_rows(f32x2{w_first, w_last}, light2);
+      if (rf_ends.x == rf_ends.y) {
+        const uint32_t r8 = (uint32_t)(int)rf_ends.x << 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) ci[k] = r8 | (texel[k] & 0xFFu);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const f32x2 px = {px0 + (float)(2 * p), px0 + (float)(2 * p + 1)};
+          const f32x2 rows = colormap_rows(exact_rcp2(pk_fma(splat(wa), px, splat(row_w))), light2);
+          ci[2 * p] = ((uint32_t)(int)rows.x << 8) | (texel[2 * p] & 0xFFu);
+          ci[2 * p + 1] = ((uint32_t)(int)rows.y << 8) | (texel[2 * p + 1] & 0xFFu);
+        }
+      }
+    }
+    uint32_t c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = cmap[ci[k]];
+    const uint32_t out0 = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24), out1 = c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24);
+    const bool inside = xin & (y < (uint32_t)height);
+    if (inside) *reinterpret_cast<uint2 *>(pfb + ((size_t)y * (size_t)width + (size_t)(qx0 + lc8))) = make_uint2(out0, out1);
+    // rare: what fragment_kernel hands to its general body goes to fixup_kernel's general rule, pixel by pixel
+    const bool leak = MASKED && (any_texel & 0x8000u) != 0u;
+    if (inside & (leak | !mod_ok)) {
+#pragma unroll 1
+      for (uint32_t k = 0; k < 8u; k++)
+        if (!mod_ok || (texel[k] & 0x8000u)) queue_fixup(fc, pose, y * (uint32_t)width + qx0 + lc8 + k);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) QUAD_OCCUPANCY void fragment_quadrant_kernel(
+    const FragConst *__restrict__ fc, const uint16_t *__restrict__ texels, const uint8_t *__restrict__ colormap,
+    const TriRec *__restrict__ recs, uint32_t cap, uint32_t *__restrict__ qtab, uint32_t n_poses, uint32_t groups_per_pose,
+    uint32_t tiles_x, uint32_t n_tiles, int width, int height, uint8_t *__restrict__ fb) {
+  __shared__ uint8_t cmap[32 * 256];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(colormap);
+    uint4 *dst = reinterpret_cast<uint4 *>(cmap);
+#pragma unroll
+    for (uint32_t k = threadIdx.x; k < 512u; k += 256u) dst[k] = src[k];
+  }
+  __syncthreads();
+  // blockIdx -> (pose, group of tiles): all groups of a pose on one XCD (b % 8), like the other kernels
+  const uint32_t g = blockIdx.x >> 3;
+  const uint32_t pose = (g / groups_per_pose) * 8u + (blockIdx.x & 7u);
+  const uint32_t grp = g % groups_per_pose;
+  if (pose >= n_poses) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const TriRec *prec = recs + (size_t)pose * cap;
+  uint32_t *ptab = qtab + (size_t)pose * n_tiles * 4u;
+  char *pfb = reinterpret_cast<char *>(fb) + (size_t)pose * (size_t)width * (size_t)height;
+  const char *tb = reinterpret_cast<const char *>(texels);
+#pragma unroll 1
+  for (uint32_t i = 0; i < QUAD_TILES_PER_WAVE; i++) {
+    const uint32_t t = (grp * 4u + wave) * QUAD_TILES_PER_WAVE + i;
+    if (t >= n_tiles) break;  // (wave-uniform)
+    const uint32_t ty = (uint32_t)(((float)t + 0.5f) / (float)tiles_x), tx = t - ty * tiles_x;  // (t < 2^16: exact)
+    const uint4 e4 = *reinterpret_cast<const uint4 *>(ptab + (size_t)t * 4u);  // the tile's four entries: one scalar load
+#pragma unroll 1
+    for (uint32_t q = 0; q < 4u; q++) {
+      const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q == 0u ? e4.x : (q == 1u ? e4.y : (q == 2u ? e4.z : e4.w))));
+      const uint32_t qx0 = tx * 64u + (q & 1u) * 32u, qy0 = ty * 64u + (q >> 1) * 32u;
+#ifdef RDOOM_FRAG_STATS
+      if (lane == 0u && qx0 < (uint32_t)width && qy0 < (uint32_t)height) atomicAdd(&g_frag_stats[ent == NONE ? 3 : 4], 1ull);
+#endif
+      // (the rasteriser writes no entry for a quadrant outside the frame: position first, then the entry)
+      if (qx0 >= (uint32_t)width || qy0 >= (uint32_t)height || ent == NONE) continue;
+      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[ent].s);
+      const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+      const uint32_t rflags = prec[ent].r.flags;
+      const uint32_t flags = r3.z;
+#ifdef RDOOM_FRAG_STATS
+      if (lane == 0u) {
+        if (!(flags & SHADE_FAST)) atomicAdd(&g_frag_stats[5], 1ull);
+        else if (flags & SHADE_NP2) atomicAdd(&g_frag_stats[6], 1ull);
+        else if (rflags & RASTER_MASKED_ANY) atomicAdd(&g_frag_stats[7], 1ull);
+      }
+#endif
+      if ((flags & SHADE_FAST) == 0u) continue;  // sky, decor, tile sizes the packed arithmetic does not cover
+      // 1/w at the four corner pixels, evaluated as the pixels evaluate it
+      const float wa = __uint_as_float(r0.x), wb = __uint_as_float(r0.y), wc = __uint_as_float(r0.z);
+      const float xl = (float)qx0 + 0.5f, xh = (float)qx0 + 31.5f, yl = (float)qy0 + 0.5f, yh = (float)qy0 + 31.5f;
+      const float rwl = fmaf(wb, yl, wc), rwh = fmaf(wb, yh, wc);
+      const uint32_t o0 = __float_as_uint(fmaf(wa, xl, rwl)) - 0x0D800000u, o1 = __float_as_uint(fmaf(wa, xh, rwl)) - 0x0D800000u,
+                     o2 = __float_as_uint(fmaf(wa, xl, rwh)) - 0x0D800000u, o3 = __float_as_uint(fmaf(wa, xh, rwh)) - 0x0D800000u;
+      // (the bit patterns of [2^-100, 2^100] are the integers [0x0D800000, 0x71800000]; negative numbers and NaNs land above)
+      if ((uint32_t)__builtin_amdgcn_readfirstlane((int)max(max(o0, o1), max(o2, o3))) > 0x71800000u - 0x0D800000u) continue;
+      const bool masked = (rflags & RASTER_MASKED_ANY) != 0u;
+#if RDOOM_QUAD_NP2
+      if (flags & SHADE_NP2) {
+        if (masked)
+          shade_quadrant<true, true>(fc, cmap, tb, pfb, pose, r0, r1, r2, r3, qx0, qy0, lane, width, height);
+        else
+          shade_quadrant<true, false>(fc, cmap, tb, pfb, pose, r0, r1, r2, r3, qx0, qy0, lane, width, height);
+      } else
+#else
+      if (flags & SHADE_NP2) continue;  // integer tile sizes that are not powers of two: fragment_kernel certifies their mod
+#endif
+      {
+        if (masked)
+          shade_quadrant<false, true>(fc, cmap, tb, pfb, pose, r0, r1, r2, r3, qx0, qy0, lane, width, height);
+        else
+          shade_quadrant<false, false>(fc, cmap, tb, pfb, pose, r0, r1, r2, r3, qx0, qy0, lane, width, height);
+      }
+      if (lane == 0u) ptab[(size_t)t * 4u + q] = ent | QTAB_HANDLED;
+    }
+  }
+}
+
+// =================================================================================================
 // Kernel 4: fixup.  Re-resolves the (rare) pixels queued by the fragment kernel with the general rule
 // R1..R6 applied to every candidate of the pixel's tile: lanes = candidates, lexicographic wave-min of
 // (d24, primitive), then the winner is shaded.  One wave per queued pixel; the list is usually empty.
@@ -577,7 +868,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
       unsigned long long key = ~0ull;
       uint32_t rec = NONE;
       if (e < hdr.y) {
-        rec = binned ? (entries[(size_t)pose * entry_cap + hdr.x + e] & 0x0FFFFFFFu) : sorted[(size_t)pose * cap + e].z;
+        rec = binned ? (entries[(size_t)pose * entry_cap + hdr.x + e] & ENTRY_REC_MASK) : sorted[(size_t)pose * cap + e].z;
         const RasterRec r = prec[rec].r;
         const int x0 = (int)(r.bb0 & 0xFFFFu), y0 = (int)(r.bb0 >> 16), x1 = (int)(r.bb1 & 0xFFFFu),
                   y1 = (int)(r.bb1 >> 16);
@@ -644,6 +935,12 @@ FragmentPlan plan_fragment(int width, int height, bool have_qtab) {
   // With leak_mod (tests) the kernel sends every block through its visibility words, so they must all be there;
   // keep_vis (tests, A/B runs) asks for them outright.
   p.skip_described_vis = p.qtab_mode != 0u && p.leak_mod == 0u && !dbg.keep_vis;
+  // the whole-quadrant kernel runs first and marks what it shaded in the table: only where fragment_kernel reads the table
+  // (and not under leak_mod, which sends every pixel through the general rule); rows must divide into 8-pixel runs
+  // -- an alternative path, OFF by default (the hook "qpath" switches it on): measured in round 4, the two kernels together are
+  // 10 % slower than fragment_kernel alone (the quadrant kernel needs 211 VALU instructions per 8-pixel run
+  // where fragment_kernel's wave-uniform body needs 275, and what is left for fragment_kernel are the expensive blocks)
+  p.quadrant_path = p.qtab_mode != 0u && p.leak_mod == 0u && dbg.qpath && width % 8 == 0;
   return p;
 }
 
@@ -652,7 +949,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
                              int width, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
                              const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
                              bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
-                             uint2 *fix_list, uint32_t fix_cap, const uint32_t *qtab, void *d_frag_const,
+                             uint2 *fix_list, uint32_t fix_cap, uint32_t *qtab, void *d_frag_const,
                              bool *frag_const_ready, const FragmentPlan &plan) {
   const uint32_t n = n_poses;
   const int W = width, H = height;
@@ -694,6 +991,13 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
     HIP_TRY(hipMemcpy(d_frag_const, &h, sizeof h, hipMemcpyHostToDevice));
     *frag_const_ready = true;
   }
+  if (qtab && plan.quadrant_path) {  // described quadrants first: whole quadrants, one record each (marks them QTAB_HANDLED)
+    const uint32_t n_tiles = (uint32_t)(tiles_x * tiles_y), groups = (n_tiles + 4u * QUAD_TILES_PER_WAVE - 1u) / (4u * QUAD_TILES_PER_WAVE);
+    const uint64_t qgrid = (uint64_t)((n + 7) / 8) * 8ull * groups;
+    if (qgrid > 0x7FFFFFFFull || n_tiles >= (1u << 16)) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
+    hipLaunchKernelGGL(fragment_quadrant_kernel, dim3((uint32_t)qgrid), dim3(256), 0, st, static_cast<const FragConst *>(d_frag_const), lv.texels,
+                       lv.colormap, recs, cap, qtab, n, groups, (uint32_t)tiles_x, n_tiles, W, H, fb);
+  }
   hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(64 * FRAG_WAVES), 0, st, static_cast<const FragConst *>(d_frag_const), lv.texels,
                      lv.colormap, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp, qpr, wbpr, wbpp, bwl, W, H, fb, debug_leak_mod, qtab,
                      qtab_mode, (uint32_t)tiles_x, (uint32_t)(tiles_x * tiles_y));
@@ -705,6 +1009,8 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
     unsigned long long h[16];
     (void)hipStreamSynchronize(st);
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_frag_stats), sizeof h);
+    fprintf(stderr, "[frag stats] quadrants in the frame: undescribed %llu, described %llu (not shaded by the quadrant kernel: sky / decor / ineligible sizes %llu, non-power-of-two size %llu, masked texture %llu) | blocks of fragment_kernel: walked %llu, skipped %llu, walked with one handled half %llu\n",
+            h[3], h[4], h[5], h[6], h[7], h[0], h[1], h[2]);
     fprintf(stderr, "[frag stats] runs %llu: to the general body %llu (%.2f %%): mixed %llu, rw out of range %llu, mod uncertified %llu, transparent texel %llu, other (decor, ineligible sizes) %llu\n", h[8], h[9], 100.0 * h[9] / h[8], h[10], h[11], h[12], h[13], h[9] - h[10] - h[11] - h[12] - h[13]);
   }
 #endif

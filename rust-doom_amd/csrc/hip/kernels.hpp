@@ -41,6 +41,8 @@ struct FragmentPlan {
   uint32_t bwl, chunk, leak_mod, qtab_mode;
   // the rasteriser may leave out the visibility words of quadrants the table describes: every reader consults the table first
   bool skip_described_vis;
+  // fragment_quadrant_kernel shades the described quadrants whose record qualifies before fragment_kernel runs
+  bool quadrant_path;
 };
 FragmentPlan plan_fragment(int width, int height, bool have_qtab);
 // Kernels 3 + 4: fragment kernel -> palette indices, then the alpha-leak fixup (fragment.hip)
@@ -49,7 +51,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
                              int width, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
                              const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
                              bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
-                             uint2 *fix_list, uint32_t fix_cap, const uint32_t *qtab, void *d_frag_const,
+                             uint2 *fix_list, uint32_t fix_cap, uint32_t *qtab, void *d_frag_const,
                              bool *frag_const_ready, const FragmentPlan &plan);  // d_frag_const: fragment_const_bytes() of device memory owned by the batch
 size_t fragment_const_bytes();
 

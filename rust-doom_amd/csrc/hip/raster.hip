@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
     if (i < count) {
       if (binned) {
         const uint32_t e = pent[i];
-        cand = e & 0x0FFFFFFFu;
+        cand = e & ENTRY_REC_MASK;
         qb = e >> 28;  // exact quadrant tests done by the binning kernel
       } else {
         // pose without complete bins: every visible triangle is a candidate; bbox, then the exact quadrant tests
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       myrq = 0u, zpa = zpb = zpc = 0u, dnq0 = dnq1 = dnq2 = dnq3 = NONE;
       if (have) {
         const uint32_t e = myq[lane];
-        const uint32_t myrec = e & 0x00FFFFFFu;
+        const uint32_t myrec = e & ENTRY_REC_MASK;
         uint32_t myqb = e >> 28;
         const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[myrec]);
         const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3];

@@ -17,6 +17,14 @@ namespace rdoom_dev {
 using namespace rdoom_fm;
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+// A tile-list entry is record index | quadrant bits << 28; a quadrant-table entry is record index | QTAB_HANDLED (or NONE).
+// One mask for every reader: a level has fewer than 2^24 triangles (rdoom_level_create checks).
+constexpr uint32_t ENTRY_REC_MASK = 0x00FFFFFFu;
+// Quadrant table, bit 24: fragment_quadrant_kernel has already shaded every pixel of this quadrant (it runs before
+// fragment_kernel, which then skips the blocks that lie in handled quadrants).  NONE has the bit set too: test NONE first.
+constexpr uint32_t QTAB_HANDLED = 1u << 24;
+__host__ __device__ inline bool qtab_handled(uint32_t e) { return e != NONE && (e & QTAB_HANDLED) != 0u; }
+__host__ __device__ inline uint32_t qtab_record(uint32_t e) { return e == NONE ? NONE : (e & ENTRY_REC_MASK); }
 constexpr int TILE_W = 64, TILE_H = 64;  // one wavefront per tile: four 32x32 quadrants in turn, 4x4 pixels per lane
 
 // ---- level-constant triangle record (built once per level on the host) -----------------------

@@ -376,6 +376,9 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
   if (e == hipSuccess) e = hipMalloc(&b->d_frag_const, fragment_const_bytes());
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_qtab, sizeof(uint32_t) * 4u * (size_t)b->n_tiles * max_poses);
+  // (the rasteriser never writes the entries of quadrants that lie outside the frame: NONE from the start, so that the
+  // table is self-consistent for every reader)
+  if (e == hipSuccess) e = hipMemset(b->d_qtab, 0xFF, sizeof(uint32_t) * 4u * (size_t)b->n_tiles * max_poses);
   if (e == hipSuccess) {  // sky.frag:13's ndc per column / row, same two operations as the per-pixel form
     std::vector<float> ndc(width + height);
     for (uint32_t i = 0; i < width; i++) ndc[i] = ((float)i + 0.5f) / (0.5f * (float)width) - 1.0f;

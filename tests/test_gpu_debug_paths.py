@@ -11,7 +11,10 @@ process sets its own, they are process-wide).  Every hook selects an equivalent 
   no_qtab=1      the fragment kernel ignores the rasteriser's quadrant table ("every pixel of this 32 x 32 quadrant shows
                  record r") and reads the visibility words of every block, as it did before the table existed;
   keep_vis=1     the rasteriser writes the visibility words of every quadrant, also of those its table describes (by default it
-                 leaves them out and every reader asks the table first).
+                 leaves them out and every reader asks the table first);
+  qpath=1        the whole-quadrant fragment kernel runs first (fragment_quadrant_kernel shades the described quadrants whose record
+                 qualifies -- queueing uncertified-mod runs and transparent texels for fixup_kernel -- and fragment_kernel skips
+                 the blocks that lie in them; off by default: measured slower than fragment_kernel alone).
 Each child renders another set of poses into its batch before the checked render: whatever the checked render does not write
 holds another frame's values.  The image is checked with and without primitive ids."""
 import os
@@ -85,7 +88,9 @@ def test_fragment_wave_block_shapes(bw):
 @pytest.mark.parametrize('hooks', [{'no_qtab': 1}, {'frag_bw': 2}, {'frag_bw': 2, 'no_qtab': 1}, {'frag_bw': 3, 'frag_nq': 1},
                                    {'frag_bw': 4, 'frag_nq': 1}, {'frag_bw': 2, 'no_bins': 1}, {'frag_bw': 3, 'vis32': 1},
                                    {'keep_vis': 1}, {'keep_vis': 1, 'frag_bw': 2}, {'leak_mod': 5}, {'leak_mod': 3, 'frag_bw': 2},
-                                   {'frag_bw': 5}, {'frag_bw': 1}])
+                                   {'frag_bw': 5}, {'frag_bw': 1}, {'qpath': 1}, {'qpath': 1, 'frag_bw': 2},
+                                   {'qpath': 1, 'keep_vis': 1}, {'qpath': 1, 'vis32': 1, 'no_bins': 1}, {'frag_nq': 1},
+                                   {'frag_bw': 2, 'keep_vis': 1, 'vis32': 1}])
 def test_quadrant_table_paths(hooks):
     """the table serves 32-pixel-wide blocks (one quadrant) and 64-pixel-wide ones (two quadrants side by side), with 8- and
     4-pixel runs per lane; frames whose right / top quadrants are partly outside (1000 x 520 = 15.6 x 8.1 tiles).  Where the
@@ -104,6 +109,15 @@ def test_frame_sizes_around_the_tile_grid(size):
     assert bad == 0, size
     bad, _ = run_child({'no_qtab': 1}, ('4', str(size[0]), str(size[1]), '2'))
     assert bad == 0, size
+
+
+@pytest.mark.parametrize('args', [('0', '1920', '1080', '3'), ('4', '1280', '720', '3'), ('7', '640', '400', '4')])
+def test_quadrant_path_at_larger_frames(args):
+    """qpath=1 (the whole-quadrant fragment kernel + fragment_kernel skipping what it shaded) on frames with many described
+    quadrants: masked wall textures (opacity test, leaks queued for fixup_kernel), integer tile sizes (certified mod, failures
+    queued), partial quadrants at the frame's bottom (1080 = 33.75 x 32)"""
+    bad, _ = run_child({'qpath': 1}, args)
+    assert bad == 0, args
 
 
 def test_child_case_plain():
