@@ -73,6 +73,9 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-sample', type=int, default=512, help='poses rendered by the CPU oracle (0 = skip)')
     ap.add_argument('--debug', action='append', default=[], metavar='NAME=VALUE',
                     help='experiment: rdoom_debug_set hook (an equivalent path: same image), e.g. frag_bw=2; repeatable')
+    ap.add_argument('--other', choices=('auto', 'on', 'off'), default='auto',
+                    help='short passes over BASELINE configs 2 / 4 / 5 after the headline (`other_workloads` on the JSON line); '
+                         'auto: with the default workload on one GPU')
     ap.add_argument('--dry-run', action='store_true',
                     help='everything but the device work (rank launch, pose partition, barrier): for hosts without a GPU; prints no value')
     return ap.parse_args(argv)
@@ -103,9 +106,85 @@ def kernel_source_digest():
 
 
 def workload_key(args, levels):
+    """names the WORKLOAD (level, frame, poses): PMC records are keyed on it.  How it was timed is `measurement_key`."""
     return '%s|levels=%s|%dx%d|poses=%d|tv=%d' % ('big' if args.big else (os.path.basename(args.iwad) if args.iwad else 'synth'),
                                                    ','.join(map(str, levels)), args.width, args.height, args.poses,
                                                    int(args.time_varying))
+
+
+def measurement_key(args, levels):
+    """workload + how `value` was timed: round-over-round comparisons must not mix single-stream values (rounds 1-2, and
+    `single_stream.value` since) with the overlapped default (`value` since round 3)"""
+    return '%s|streams=%d' % (workload_key(args, levels), args.streams)
+
+
+OTHER_WORKLOADS = (   # BASELINE configs 2 / 4 / 5 (and the 4K frame) in short: what the driver's one command would otherwise never see
+    dict(name='config 4 on one GPU: E1M1..E1M9, one batch per level', levels=list(range(9)), big=False, width=1920, height=1080, poses=512, tv=False),
+    dict(name='config 5 class: 10x-E1M1 (MAP29 stand-in), pose i at time i/35 s with its own light table', levels=[0], big=True, width=3840, height=2160, poses=256, tv=True),
+    dict(name='config 2 frame size: E1M1', levels=[0], big=False, width=320, height=200, poses=8192, tv=False),
+    dict(name='E1M1', levels=[0], big=False, width=3840, height=2160, poses=256, tv=False),
+)
+
+
+def quick_line(rd, torch, sharding, wad, spec, streams, steps=5, warmup=1):
+    """One short measurement of another workload, timed like the headline: the poses of every level as `streams` sub-batches on
+    `streams` HIP streams (value), then as ONE batch on one stream for the per-kernel times."""
+    w, h, n = spec['width'], spec['height'], spec['poses']
+    work, full, closers = [], [], []
+    for index in spec['levels']:
+        built = wad.build_level(index, gpu_tessellation=True)
+        level = rd.DeviceLevel(built)
+        poses = sharding.pose_sweep(rd, built, n, w, h)
+        if spec['tv']:
+            poses['time'] = (np.arange(n) / 35.0).astype(np.float32)
+            lights = np.stack([built.lights_at(float(t)) for t in poses['time']])
+        else:
+            lights = built.lights_at(0.0)
+        for part in range(streams):
+            lo, hi = sharding.shard_range(n, part, streams)
+            if hi > lo:
+                b = rd.Batch(level, w, h, hi - lo)
+                work.append((b, poses[lo:hi], lights[lo:hi] if spec['tv'] else lights, torch.cuda.Stream()))
+                closers.append(b)
+        b = rd.Batch(level, w, h, n)
+        full.append((b, poses, lights, None))
+        closers += [b, level, built]
+
+    def run(items, k):
+        for _ in range(k):
+            for b, p, l, st in items:
+                b.render_profiled(p, l, stream=st.cuda_stream if st is not None else None)
+
+    def collect(items):
+        acc = {'setup_ms': 0.0, 'raster_ms': 0.0, 'fragment_ms': 0.0}
+        for b, _p, _l, _s in items:
+            t = b.collect_timings()
+            for k in acc:
+                acc[k] += t[k]
+        return acc
+
+    run(work, warmup)
+    collect(work)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(work, steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    collect(work)
+    run(full, warmup)
+    collect(full)
+    torch.cuda.synchronize()
+    run(full, steps)
+    torch.cuda.synchronize()
+    acc = collect(full)
+    px = n * w * h * len(spec['levels'])
+    frag = acc['fragment_ms'] / steps
+    for c in closers:
+        c.close()
+    return {'workload': '%s, %d poses%s at %dx%d' % (spec['name'], n, ' per level' if len(spec['levels']) > 1 else '', w, h),
+            'value': round(px * steps / elapsed / 1e6, 1), 'unit': 'Mpixels/s', 'ms_per_step': round(elapsed / steps * 1e3, 3), 'steps': steps,
+            'kernels_ms': {k[:-3]: round(acc[k] / steps, 3) for k in ('setup_ms', 'raster_ms', 'fragment_ms')},
+            'roofline_frac': round(px * ALG_READ_BYTES_PER_PIXEL / (frag * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frag > 0 else None}
 
 
 def usable_cores():
@@ -217,7 +296,7 @@ def main():
     else:
         lo, hi = rank * args.poses, (rank + 1) * args.poses      # every GPU its own batch
     n_mine = hi - lo
-    work, work_full = [], []
+    work, work_full, tstreams = [], [], []
     t_build = 0.0
     for index in levels:
         t0 = time.perf_counter()
@@ -237,7 +316,10 @@ def main():
                 lights = np.stack([built.lights_at(float(t)) for t in times]) if phi > plo else np.zeros((0, 256), np.uint8)
             else:
                 lights = built.lights_at(0.0)
-            stream = torch.cuda.Stream().cuda_stream if args.streams > 1 else None
+            tstream = torch.cuda.Stream() if args.streams > 1 else None
+            stream = tstream.cuda_stream if tstream is not None else None
+            if tstream is not None and all(tstream is not x for x in tstreams):
+                tstreams.append(tstream)
             work.append((built, level, batch, poses, lights, stream))
         if args.streams > 1:   # the whole pose range as ONE batch, for the single-stream pass after the timed region
             poses = np.concatenate([w[3] for w in work[-args.streams:]])
@@ -273,14 +355,26 @@ def main():
             collect(None)
     collect(None)
     barrier()
+    # per-step spread: an event at the end of every step on every render stream (GPU time stamps; nothing waits for them)
+    mark_streams = tstreams if tstreams else [torch.cuda.current_stream()]
+    ev_start = torch.cuda.Event(enable_timing=True)
+    ev_start.record(mark_streams[0])
+    step_marks = []
     t_start = time.perf_counter()
     acc = {'setup_ms': 0.0, 'raster_ms': 0.0, 'fragment_ms': 0.0}
     for i in range(args.steps):
-        if step(i):
+        flush = step(i)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in mark_streams]
+        for e, st in zip(marks, mark_streams):
+            e.record(st)
+        step_marks.append(marks)
+        if flush:
             collect(acc)   # (a host synchronisation every 60 steps)
     barrier()
     elapsed = time.perf_counter() - t_start
     collect(acc)
+    ends = [max(ev_start.elapsed_time(e) for e in marks) for marks in step_marks]   # ms since the start mark, per step
+    step_ms = [b - a for a, b in zip([0.0] + ends[:-1], ends)]
     elapsed = sharding.max_over_ranks(elapsed, dist, 'cuda' if backend == 'nccl' else 'cpu')
     # With several streams the kernels of different sub-batches run side by side: the step time above is what the metric
     # asks for, but a kernel's own duration cannot be read off overlapped events.  The same poses are therefore rendered
@@ -309,7 +403,7 @@ def main():
         my_px_per_step = n_mine * frame_px * len(levels)
         frag = acc['fragment_ms'] / args.steps             # this rank's fragment-kernel time per step (all levels)
         achieved = my_px_per_step * ALG_READ_BYTES_PER_PIXEL / (frag * 1e-3) / 1e9 if frag > 0 else 0.0
-        traffic = frac_actual = None
+        traffic = frac_actual = valu = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_fragment_latest.json')
         if os.path.exists(pmc) and world == 1:
             try:
@@ -317,8 +411,27 @@ def main():
                 if rec.get('workload') == workload_key(args, levels) and rec.get('kernel_sources') == kernel_source_digest():
                     traffic = rec.get('hbm_bytes_per_launch')
                     frac_actual = round(traffic / (frag * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    valu = rec.get('valu')   # the VALU-issue roofline of the hot kernels (same passes: see tools/profile_collect.py)
             except Exception:
                 traffic = None
+        # BASELINE configs 2 / 4 / 5 in short, on the same box, same library, same timing scheme (N = 1 only): the headline's
+        # scratch is released first
+        other_lines = None
+        default_workload = (levels == [0] and not args.big and not args.iwad and not args.time_varying and not args.debug and
+                            (args.width, args.height, args.poses) == (1920, 1080, 1024))
+        if world == 1 and (args.other == 'on' or (args.other == 'auto' and default_workload)):
+            for item in work + work_full:
+                item[2].close()
+            other_lines = []
+            wads = {}
+            for spec in OTHER_WORKLOADS:
+                key = bool(spec['big'])
+                if key not in wads:
+                    wads[key] = rd.Wad(synthetic.ensure_big_wad() if key else synthetic.ensure_wad(), synthetic.META_PATH)
+                try:
+                    other_lines.append(quick_line(rd, torch, sharding, wads[key], spec, max(args.streams, 1)))
+                except Exception as e:  # noqa: BLE001  (a failing extra must not take the headline with it: it says so instead)
+                    other_lines.append({'workload': spec['name'], 'error': repr(e)})
         cpu = None
         if args.cpu_sample > 0 and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             from oracle import raster
@@ -380,13 +493,25 @@ def main():
                                            'a single-stream pass after the timed region (the same poses as ONE batch, %d steps, one launch per kernel and step): '
                                            'with %d streams the kernels overlap, so their sum exceeds ms_per_step' % (args.steps, args.streams)),
                        'streams': args.streams, **({'debug': args.debug} if args.debug else {}),
-                       'workload_key': workload_key(args, levels), 'kernel_sources': kernel_source_digest()},
+                       'workload_key': workload_key(args, levels), 'measurement_key': measurement_key(args, levels),
+                       'comparable_with_rounds_1_2': 'single_stream.value' if args.streams > 1 else 'value',
+                       'kernel_sources': kernel_source_digest()},
+            # spread of the timed steps (GPU time stamps at the end of every step, max over the render streams)
+            'value_spread': {'step_ms_min': round(min(step_ms), 3), 'step_ms_median': round(float(np.median(step_ms)), 3),
+                             'step_ms_max': round(max(step_ms), 3),
+                             'value_min': round(my_px_per_step * world / max(step_ms) / 1e3, 1), 'value_max': round(my_px_per_step * world / min(step_ms) / 1e3, 1),
+                             'from': 'rank 0, one event per step and render stream'},
             'roofline': {'bound': 'hbm', 'kernel': 'fragment_kernel', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          # frac: SURVEY 8(d)'s 6 B/px; frac_layout_bytes: the 2 + 2 B/px this layout keeps per pixel (the quadrant
                          # table lets uniform quadrants skip even those); frac_actual_bytes: HBM traffic by the PMC counters
                          'frac_layout_bytes': round(achieved / HBM_PEAK_GBS * LAYOUT_READ_BYTES_PER_PIXEL / ALG_READ_BYTES_PER_PIXEL, 4),
-                         'traffic': traffic, 'frac_actual_bytes': frac_actual},
+                         'traffic': traffic, 'frac_actual_bytes': frac_actual,
+                         # what binds the step: VALU issue, not HBM (PMC passes of tools/profile_round.sh on THESE kernel sources,
+                         # null when none were taken): wave64 VALU instructions per pixel, issue cycles = SQ_ACTIVE_INST_VALU x 4 / 1024
+                         # SIMDs, frac = issue cycles / kernel cycles (GRBM_GUI_ACTIVE / 8 XCDs), per hot kernel and for the step
+                         'valu': valu},
+            'other_workloads': other_lines,
             'cpu_baseline': cpu,
         }
         if single_elapsed is not None:   # the same work without the overlap: the step the per-kernel figures add up to

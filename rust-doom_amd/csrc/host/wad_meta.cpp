@@ -5,6 +5,7 @@
 // tables.  Unknown keys are ignored, as serde does for structs without deny_unknown_fields.
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 
 #include "wad.hpp"
@@ -347,6 +348,11 @@ HeightEffectDef height_effect(const TomlValue &t) {
 
 }  // namespace
 
+static std::mutex &regex_mutex() {
+  static std::mutex m;
+  return m;
+}
+
 WadMetadata WadMetadata::from_file(const std::string &path) {
   std::ifstream f(path, std::ios::binary);
   if (!f) throw WadError(RDOOM_IO, "cannot read metadata file '" + path + "'");
@@ -363,6 +369,10 @@ WadMetadata WadMetadata::from_text(const std::string &text) {
     sky.texture_name = name_from(need(s, "texture_name", TomlValue::Str));
     sky.pattern_text = need(s, "level_pattern", TomlValue::Str).s;
     try {
+      // libstdc++'s regex compiler and matcher go through std::ctype<char>::narrow, which fills a cache inside the GLOBAL
+      // locale's facet without synchronisation: two host threads opening IWADs at the same time race on it (found by
+      // tests/test_host_threads.py under ThreadSanitizer).  Every std::regex operation of the library holds this lock.
+      std::lock_guard<std::mutex> lock(regex_mutex());
       sky.level_pattern = std::regex(sky.pattern_text, std::regex::ECMAScript);
     } catch (const std::regex_error &e) {
       meta_fail("bad level_pattern '" + sky.pattern_text + "'");
@@ -424,8 +434,11 @@ const ThingMetadata *WadMetadata::find_thing(uint16_t thing_type) const {
 
 const SkyMetadata *WadMetadata::sky_for(const WadName &level_name) const {
   const std::string text((const char *)level_name.b.data(), 8);  // WadName::as_ref keeps the NUL padding
-  for (const SkyMetadata &s : sky)
-    if (std::regex_search(text, s.level_pattern)) return &s;
+  {
+    std::lock_guard<std::mutex> lock(regex_mutex());  // (see from_text)
+    for (const SkyMetadata &s : sky)
+      if (std::regex_search(text, s.level_pattern)) return &s;
+  }
   return sky.empty() ? nullptr : &sky[0];
 }
 

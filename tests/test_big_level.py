@@ -55,14 +55,13 @@ def test_big_level_frames(big, width, height, n):
     poses[2]['modelview'] = view_matrix((lo[0] - 1.0, hi[1] + 4.0, lo[2] - 1.0), -2.4, -0.25)
     lights = lv.lights.fill_buffer_at(0.9)
     batch = rd.Batch(rd.DeviceLevel(built), width, height, n)
-    batch.enable_primitive_ids()
-    batch.render(poses, lights)
-    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    from util import render_checked
+    fb_plain, fb, prim = render_checked(batch, poses, lights)  # after a dirtying render; without and with primitive ids
     ro = raster.RasterOracle(lv)
     bad = []
     for i in range(n):
         ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], 0.9, lights, width, height, want_prim=True)
-        d = int((oprim != prim[i]).sum()), int((ofb != fb[i]).sum())
+        d = int((oprim != prim[i]).sum()), int((ofb != fb[i]).sum()) + int((ofb != fb_plain[i]).sum())
         if d != (0, 0):
             bad.append((i, d))
     assert not bad, bad[:10]
@@ -84,9 +83,8 @@ def test_big_level_4k_time_varying_with_per_pose_lights(big):
     lights = np.stack([built.lights_at(float(t)) for t in times])
     assert len({li.tobytes() for li in lights}) > 1                          # the tables really differ
     batch = rd.Batch(rd.DeviceLevel(built), width, height, n)
-    batch.enable_primitive_ids()
-    batch.render(poses, lights)
-    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    from util import render_checked
+    fb_plain, fb, prim = render_checked(batch, poses, lights)  # after a dirtying render (other poses, other light tables)
     ro = raster.RasterOracle(lv)
     from concurrent.futures import ThreadPoolExecutor
 
@@ -97,5 +95,5 @@ def test_big_level_4k_time_varying_with_per_pose_lights(big):
     with ThreadPoolExecutor(n) as ex:   # (the C oracle releases the GIL: one pose per host thread)
         want = list(ex.map(one, range(n)))
     for i, (ofb, oprim) in enumerate(want):
-        assert int((oprim != prim[i]).sum()) == 0 and int((ofb != fb[i]).sum()) == 0, i
+        assert int((oprim != prim[i]).sum()) == 0 and int((ofb != fb[i]).sum()) == 0 and int((ofb != fb_plain[i]).sum()) == 0, i
         assert (fb[i] != 0).mean() > 0.5

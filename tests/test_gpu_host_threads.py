@@ -1,0 +1,131 @@
+"""GPU: the library driven from several HOST threads (SURVEY 8(b) "Threading": "a rdoom_level* is
+immutable after create => shareable; a rdoom_batch* / stream context is single-owner; one host thread per GPU").  This is
+the shape a Rust host would use -- one process, a std::thread per device / stream -- rather than one process per GPU.
+  * ONE rdoom_level shared by T = 4 threads, each with its own rdoom_batch and its own hipStream_t: concurrent render /
+    finish / read_framebuffer for several rounds (ctypes releases the GIL around every call), every frame compared with the
+    oracle;
+  * rdoom_last_error is thread-local: an error provoked on one thread is not seen by another;
+  * one thread per DEVICE when the box has at least two (skipped otherwise; tests/test_gpu_two_devices.py drives two devices
+    from one thread).
+The host-only half (rdoom_wad_open / build_level on T threads) runs under ThreadSanitizer in tests/test_host_threads.py."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+import rust_doom_amd as rd
+from oracle import raster
+from test_gpu_raster_parity import sweep_poses
+from util import dirtying_poses
+
+pytestmark = pytest.mark.gpu
+T, ROUNDS = 4, 3
+
+
+def test_shared_level_four_threads_own_batches_and_streams(oracle_levels):
+    lv = oracle_levels(3)
+    w, h, n = 320, 200, 5
+    level = rd.DeviceLevel(lv)                       # immutable after create: shared by every thread
+    lights = lv.lights.fill_buffer_at(0.25)
+    ro = raster.RasterOracle(lv)
+    hip = ctypes.CDLL('libamdhip64.so')
+    work, want = [], []
+    for t in range(T):
+        poses = sweep_poses(lv, n, w, h, seed=100 + t, time=0.25)
+        work.append(poses)
+        want.append(np.stack([ro.render(p['modelview'], p['projection'], 0.25, lights, w, h) for p in poses]))
+    errors, barrier = [], threading.Barrier(T)
+
+    def worker(t):
+        try:
+            rd.set_device(level_device)              # (hipSetDevice is per host thread)
+            stream = ctypes.c_void_p()
+            assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+            batch = rd.Batch(level, w, h, n)         # single-owner: this thread's own scratch
+            for r in range(ROUNDS):
+                barrier.wait()                       # all threads render at the same time
+                batch.render(dirtying_poses(work[t]), lights, stream=stream.value)
+                batch.render(work[t], lights, stream=stream.value)
+                batch.finish()
+                fb = batch.read_framebuffer()
+                if not np.array_equal(fb, want[t]):
+                    errors.append((t, r, int((fb != want[t]).sum())))
+            batch.close()
+            assert hip.hipStreamDestroy(stream) == 0
+        except Exception as e:  # noqa: BLE001  (reported by the main thread)
+            errors.append((t, repr(e)))
+            barrier.abort()
+
+    level_device = 0
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(600)
+    assert not errors, errors
+
+
+def test_last_error_is_thread_local(oracle_levels):
+    lib = rd.lib()
+    lib.rdoom_last_error.restype = ctypes.c_char_p
+    seen = {}
+    first, second = threading.Event(), threading.Event()
+
+    def failing():
+        count = ctypes.c_int32()
+        assert lib.rdoom_batch_finish(None) != 0     # BAD_ARG: "null argument" on THIS thread
+        seen['failing'] = lib.rdoom_last_error()
+        first.set()
+        second.wait(60)
+        seen['failing_again'] = lib.rdoom_last_error()   # still this thread's message after the other thread's calls
+        del count
+
+    def clean():
+        first.wait(60)
+        seen['clean_before'] = lib.rdoom_last_error()    # nothing failed on this thread
+        n = ctypes.c_int32()
+        assert lib.rdoom_device_count(ctypes.byref(n)) == 0
+        assert lib.rdoom_debug_set(b'no such hook', 1) != 0
+        seen['clean_after'] = lib.rdoom_last_error()
+        second.set()
+
+    a, b = threading.Thread(target=failing), threading.Thread(target=clean)
+    a.start(), b.start()
+    a.join(120), b.join(120)
+    assert seen['failing'] and b'null' in seen['failing']
+    assert not seen['clean_before']
+    assert b'no such hook' in seen['clean_after']
+    assert seen['failing_again'] == seen['failing']
+
+
+def test_one_host_thread_per_device(oracle_levels):
+    if rd.device_count() < 2:
+        pytest.skip('needs two GPUs (the driver\'s box has one)')
+    lv = oracle_levels(1)
+    w, h, n = 256, 160, 4
+    lights = lv.lights.fill_buffer_at(0.0)
+    ro = raster.RasterOracle(lv)
+    errors = []
+
+    def worker(dev):
+        try:
+            rd.set_device(dev)
+            level = rd.DeviceLevel(lv)               # one copy of the level per device (replicated)
+            batch = rd.Batch(level, w, h, n)
+            poses = sweep_poses(lv, n, w, h, seed=40 + dev)
+            for _ in range(ROUNDS):
+                batch.render(poses, lights)
+                fb = batch.read_framebuffer()
+                for i in range(n):
+                    if not np.array_equal(fb[i], ro.render(poses[i]['modelview'], poses[i]['projection'], 0.0, lights, w, h)):
+                        errors.append((dev, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append((dev, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(d,)) for d in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(600)
+    assert not errors, errors

@@ -6,7 +6,7 @@ import pytest
 
 import rust_doom_amd as rd
 from oracle import raster
-from util import META_PATH, reference_projection, view_matrix
+from util import META_PATH, reference_projection, render_checked, view_matrix
 
 pytestmark = pytest.mark.gpu
 
@@ -37,19 +37,16 @@ def run_case(lv, width, height, n, kinds, time=0.0):
     lights = lv.lights.fill_buffer_at(time)
     dev = rd.DeviceLevel(lv)
     batch = rd.Batch(dev, width, height, n)
-    batch.enable_primitive_ids()
-    batch.render(poses, lights, kinds=kinds)
-    fb = batch.read_framebuffer()
-    prim = batch.read_primitive_ids()
+    fb_plain, fb, prim = render_checked(batch, poses, lights, kinds=kinds)  # after a dirtying render; without and with primitive ids
     ro = raster.RasterOracle(lv)
     bad = []
     for i in range(n):
         ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], time, lights, width, height, kinds=kinds,
                                want_prim=True)
-        npx = int((oprim != prim[i]).sum()), int((ofb != fb[i]).sum())
-        if npx != (0, 0):
+        npx = int((oprim != prim[i]).sum()), int((ofb != fb[i]).sum()), int((ofb != fb_plain[i]).sum())
+        if npx != (0, 0, 0):
             bad.append((i, npx))
-    assert not bad, 'mismatching (pose, (prim px, colour px)): %r' % bad[:10]
+    assert not bad, 'mismatching (pose, (prim px, colour px, colour px of the path without ids)): %r' % bad[:10]
     return fb
 
 
@@ -114,15 +111,13 @@ def test_decor_billboards(oracle_levels):
     poses = np.array(poses[:24], rd.POSE)
     lights = lv.lights.fill_buffer_at(0.0)
     batch = rd.Batch(rd.DeviceLevel(lv), w, h, len(poses))
-    batch.enable_primitive_ids()
-    batch.render(poses, lights)
-    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    fb_plain, fb, prim = render_checked(batch, poses, lights)
     ro = raster.RasterOracle(lv)
     first = np.cumsum([0] + [int(d[3]) // 3 for d in lv.draws])
     decor_px = 0
     for i in range(len(poses)):
         ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], 0.0, lights, w, h, want_prim=True)
-        assert np.array_equal(oprim, prim[i]) and np.array_equal(ofb, fb[i]), i
+        assert np.array_equal(oprim, prim[i]) and np.array_equal(ofb, fb[i]) and np.array_equal(ofb, fb_plain[i]), i
         for di, d in enumerate(lv.draws):
             if d[0] == rd.KIND_DECOR:
                 decor_px += int(((oprim >= first[di]) & (oprim < first[di + 1])).sum())
@@ -150,15 +145,13 @@ def test_moving_objects(oracle_levels):
     dev = rd.DeviceLevel(lv)
     assert dev.num_objects() == n_obj
     batch = rd.Batch(dev, w, h, n)
-    batch.enable_primitive_ids()
-    batch.render(poses, lights, object_modelviews=om)
-    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    fb_plain, fb, prim = render_checked(batch, poses, lights, object_modelviews=om)
     ro = raster.RasterOracle(lv)
     moved = 0
     for i in range(n):
         ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], 0.0, lights, w, h, want_prim=True,
                                object_modelviews=om[i])
-        assert np.array_equal(oprim, prim[i]) and np.array_equal(ofb, fb[i]), i
+        assert np.array_equal(oprim, prim[i]) and np.array_equal(ofb, fb[i]) and np.array_equal(ofb, fb_plain[i]), i
         still = ro.render(poses[i]['modelview'], poses[i]['projection'], 0.0, lights, w, h)
         moved += int((still != ofb).sum())
     assert moved > 2000  # the offsets are visible
@@ -218,15 +211,13 @@ def test_sky_heavy_views(oracle_levels):
         poses[i]['projection'] = reference_projection(w, h)
     lights = lv.lights.fill_buffer_at(0.0)
     batch = rd.Batch(rd.DeviceLevel(lv), w, h, len(poses))
-    batch.enable_primitive_ids()
-    batch.render(poses, lights)
-    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    fb_plain, fb, prim = render_checked(batch, poses, lights)
     ro = raster.RasterOracle(lv)
     first = np.cumsum([0] + [int(d[3]) // 3 for d in lv.draws])
     sky_px = 0
     for i in range(len(poses)):
         ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], 0.0, lights, w, h, want_prim=True)
-        assert np.array_equal(oprim, prim[i]) and np.array_equal(ofb, fb[i]), i
+        assert np.array_equal(oprim, prim[i]) and np.array_equal(ofb, fb[i]) and np.array_equal(ofb, fb_plain[i]), i
         for di, d in enumerate(lv.draws):
             if d[0] == rd.KIND_SKY:
                 sky_px += int(((oprim >= first[di]) & (oprim < first[di + 1])).sum())

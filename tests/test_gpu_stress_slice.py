@@ -11,7 +11,7 @@ import pytest
 
 import rust_doom_amd as rd
 from oracle import raster
-from util import reference_projection, view_matrix
+from util import reference_projection, render_checked, view_matrix
 
 pytestmark = pytest.mark.gpu
 SIZES = [(640, 400), (324, 180), (1280, 720), (200, 120)]
@@ -19,15 +19,14 @@ SIZES = [(640, 400), (324, 180), (1280, 720), (200, 120)]
 
 def compare(lv, poses, lights, w, h, om=None):
     batch = rd.Batch(rd.DeviceLevel(lv), w, h, len(poses))
-    batch.enable_primitive_ids()
-    batch.render(poses, lights, object_modelviews=om)
-    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    kw = {} if om is None else {'object_modelviews': om}
+    fb_plain, fb, prim = render_checked(batch, poses, lights, **kw)  # after a dirtying render; without and with primitive ids
     ro = raster.RasterOracle(lv)
 
     def check(i):
         ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], float(poses[i]['time']), lights[i], w, h,
                                want_prim=True, object_modelviews=None if om is None else om[i])
-        return int((ofb != fb[i]).sum()), int((oprim != prim[i]).sum())
+        return int((ofb != fb[i]).sum()) + int((ofb != fb_plain[i]).sum()), int((oprim != prim[i]).sum())
 
     with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
         res = list(ex.map(check, range(len(poses))))

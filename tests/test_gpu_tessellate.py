@@ -33,8 +33,9 @@ def test_product_path_end_to_end(wad_path):
         c = cents[(i * 7) % len(cents)]
         poses[i] = rd.pose_look((c[0], c[1] + 0.41, c[2]), 1.1 * i, 0.1 * (i - 3), w, h, 0.5)
     lights = built.lights_at(0.5)
-    batch.render(poses, lights)
-    fb = batch.read_framebuffer()
+    from util import render_checked
+    fb, fb_ids, _prim = render_checked(batch, poses, lights)  # after a dirtying render; both instantiations give the same frames
+    assert np.array_equal(fb, fb_ids)
     olv = wad_oracle.build_level(wad_path, META_PATH, 2)
     ro = raster.RasterOracle(olv)
     for i in range(n):

@@ -194,8 +194,10 @@ def test_hip_matches_hand_derivation(prediction):
     poses = np.zeros(1, rd.POSE)
     poses[0]['modelview'], poses[0]['projection'] = mv, pr
     batch = rd.Batch(rd.DeviceLevel(lvl), W, H, 1)
-    batch.render(poses, lights)
-    fb = batch.read_framebuffer()[0]
+    from util import render_checked
+    fb_plain, fb_ids, _prim = render_checked(batch, poses, lights)  # after a dirtying render (the view turned by a radian)
+    assert np.array_equal(fb_plain, fb_ids)
+    fb = fb_plain[0]
     out, safe = prediction
     bad = (fb != out) & safe
     assert bad.sum() == 0, 'HIP path differs from the hand derivation at %r' % (np.argwhere(bad)[:5],)

@@ -60,9 +60,8 @@ def test_hip_matches_oracle_on_other_seeds(other_wad):
             poses = sharding.pose_sweep(rd, built, n, w, h, first=17 * index, time=t)
             lights = built.lights_at(t)
             batch = rd.Batch(level, w, h, n)
-            batch.enable_primitive_ids()
-            batch.render(poses, lights)
-            fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+            from util import render_checked
+            fb_plain, fb, prim = render_checked(batch, poses, lights)  # after a dirtying render; without and with primitive ids
             for i in range(n):
                 ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], t, lights, w, h, want_prim=True)
-                assert np.array_equal(fb[i], ofb) and np.array_equal(prim[i], oprim), (index, w, i)
+                assert np.array_equal(fb[i], ofb) and np.array_equal(fb_plain[i], ofb) and np.array_equal(prim[i], oprim), (index, w, i)

@@ -64,3 +64,39 @@ def fb_to_png(path, fb, playpal):
     """fb: (h,w) palette indices with row 0 = bottom; playpal: 768 bytes."""
     pal = np.asarray(playpal, np.uint8).reshape(256, 3)
     write_png(path, pal[fb[::-1]])
+
+
+def dirtying_poses(poses):
+    """ANOTHER pose set of the same size: every frame slot gets its neighbour's pose, turned by one radian about the view's
+    y axis (new modelview = Ry(1) o modelview; column-major).  Rendered into a batch before the checked poses, it leaves
+    another frame's visibility words, quadrant table and tile lists wherever the checked render does not write them."""
+    out = np.roll(np.array(poses, copy=True), 1)
+    c, s = np.float32(np.cos(1.0)), np.float32(np.sin(1.0))
+    ry = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], np.float32)
+    for p in out.reshape(-1):
+        m = np.asarray(p['modelview'], np.float32).reshape(4, 4).T  # column-major storage -> matrix
+        p['modelview'] = (ry @ m).T.reshape(16)
+    return out
+
+
+def render_checked(batch, poses, lights, want_prim=True, **kw):
+    """The render every HIP-vs-oracle assertion goes through.  Since the rasteriser leaves out the
+    visibility words of quadrants its table describes, a reader of a word nobody wrote must meet ANOTHER frame's record, not
+    the zeros of a fresh allocation -- so the batch is dirtied by a render of other poses first; and both instantiations are
+    checked: the one without primitive ids (the path bench.py times), then, dirtied again, the one with them.
+    Returns (framebuffers of the plain path, framebuffers of the id path, primitive ids) -- callers compare all three with the
+    oracle.  kw: kinds=, object_modelviews= as Batch.render takes them."""
+    other = dirtying_poses(poses)
+    olights = lights
+    if getattr(lights, 'ndim', 1) == 2 and len(lights) == len(np.atleast_1d(poses)):
+        olights = np.roll(lights, 1, axis=0)
+    dirty_kw = {k: v for k, v in kw.items() if k != 'object_modelviews'}   # (the dirtying frames need no displaced doors)
+    batch.render(other, olights, **dirty_kw)
+    batch.render(poses, lights, **kw)
+    fb_plain = batch.read_framebuffer()
+    if not want_prim:
+        return fb_plain, None, None
+    batch.enable_primitive_ids()
+    batch.render(other, olights, **dirty_kw)
+    batch.render(poses, lights, **kw)
+    return fb_plain, batch.read_framebuffer(), batch.read_primitive_ids()

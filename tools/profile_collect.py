@@ -36,6 +36,47 @@ for f in files:
     for row in csv.DictReader(open(f)):
         if 'fragment_kernel' in row['Kernel_Name'] and row['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
             vals[row['Counter_Name']].append(float(row['Counter_Value']))
+# the VALU-issue roofline of the two hot kernels ("the yardstick no longer measures what binds the step"):
+# per launch, means over the dispatches of the whole batch
+def kernel_counters(key):
+    acc = collections.defaultdict(list)
+    for f in files:
+        per = collections.defaultdict(dict)
+        for row in csv.DictReader(open(f)):
+            name = row['Kernel_Name']
+            if key in name and ('quadrant' in key) == ('fragment_quadrant' in name):
+                per[row['Dispatch_Id']][row['Counter_Name']] = per[row['Dispatch_Id']].get(row['Counter_Name'], 0.0) + float(row['Counter_Value'])
+                per[row['Dispatch_Id']]['_grid'] = int(row['Grid_Size'])
+        if per:
+            big = max(d['_grid'] for d in per.values())
+            for d in per.values():
+                if d['_grid'] == big:
+                    for c, v in d.items():
+                        acc[c].append(v)
+    return {c: sum(v) / len(v) for c, v in acc.items()}
+
+
+def valu_roofline(pixels):
+    out, step_issue, step_insts = {}, 0.0, 0.0
+    for key in ('fragment_kernel', 'fragment_quadrant_kernel', 'raster_wave_kernel'):
+        c = kernel_counters(key)
+        if not all(k in c for k in ('SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'GRBM_GUI_ACTIVE')):
+            continue
+        cycles = c['GRBM_GUI_ACTIVE'] / 8.0                  # the counter sums the 8 XCDs
+        issue = c['SQ_ACTIVE_INST_VALU'] * 4.0 / 1024.0      # quad-cycles over all SIMDs -> cycles per SIMD
+        out[key] = {'insts_per_pixel': round(c['SQ_INSTS_VALU'] * 64.0 / pixels, 2), 'wave_insts_per_launch': c['SQ_INSTS_VALU'],
+                    'issue_cycles': round(issue), 'kernel_cycles': round(cycles), 'frac': round(issue / cycles, 4)}
+        step_issue += issue
+        step_insts += c['SQ_INSTS_VALU']
+    if out:
+        out['note'] = ('lane-instructions per output pixel = SQ_INSTS_VALU x 64 / pixels; issue cycles = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / 1024 SIMDs; '
+                       'kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; separate --pmc passes of bench.py --streams 1 (tools/profile_round.sh).  The counter '
+                       'charges every VALU instruction one quad-cycle: tools/ubench_valu.hip measures 2.4 cycles for v_fma/mul/add_f32, v_add_u32, v_and/or_b32 '
+                       'and 4.2 for the rest, so the fraction is an upper bound of the true issue share')
+        out['step'] = {'insts_per_pixel': round(step_insts * 64.0 / pixels, 2), 'issue_cycles': round(step_issue)}
+    return out
+
+
 fetch = sum(vals['FETCH_SIZE']) / len(vals['FETCH_SIZE'])
 write = sum(vals['WRITE_SIZE']) / len(vals['WRITE_SIZE'])
 bench = json.loads(line)
@@ -47,6 +88,7 @@ out = {'kernel': 'fragment_kernel', 'poses': bench['config']['poses_per_gpu'], '
        'hbm_bytes_per_launch': 2.0 * fetch * 1024.0 + write * 1024.0,
        'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950, 16 B/lane reads)',
        'round': rnd}
+out['valu'] = valu_roofline(bench['config']['poses_per_gpu'] * bench['config']['width'] * bench['config']['height']) or None
 json.dump(out, open(os.path.join(dst, 'pmc_fragment_latest.json'), 'w'), indent=1)
 print(json.dumps(out))
 
