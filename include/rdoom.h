@@ -326,6 +326,15 @@ rdoom_status rdoom_built_floor_centroids(const rdoom_built *built, const float *
  * engine/src/projections.rs:93-101; engine/src/renderer.rs:78-87). */
 rdoom_status rdoom_pose_look(const float eye[3], float yaw, float pitch, uint32_t width, uint32_t height, float time,
                              rdoom_pose *out_pose);
+/* The same camera in the REFERENCE'S OWN ARITHMETIC, binary32 throughout: the player entity's Decomposed { rot =
+ * Quaternion::from(Euler { x: pitch, y: yaw, z: 0 }), disp = pos } (game/src/player.rs:124-131) concatenated with the camera
+ * child at (0, 0.12, 0) (player.rs:325-335, engine/src/transforms.rs:121), inverted and turned into a matrix as
+ * Renderer::update does (engine/src/renderer.rs:78-87), cgmath 0.18.0's published formulas restated; the projection from
+ * f = cot(fovy / 2) in binary32.  `pos` is the PLAYER's position (level.start_pos()), not the eye: the camera height is added
+ * here.  rdoom_pose_look (double precision, rounded once) stays the helper of the seeded sweeps; the two agree to a few
+ * units in the last place (tests/test_pose_helpers.py). */
+rdoom_status rdoom_pose_from_player(const float pos[3], float yaw, float pitch, uint32_t width, uint32_t height, float time,
+                                    rdoom_pose *out);
 
 #ifdef __cplusplus
 }

@@ -435,6 +435,8 @@ class TextureDirectory:
         return out
 
     def _read_textures(self, buf):  # tex.rs:499-592
+        if len(buf) < 4:  # read_u32 fails: CorruptWad("Missing number of textures") (tex.rs:505-508) -- an empty TEXTURE2, say
+            raise WadError('missing number of textures')
         n = struct.unpack_from('<I', buf, 0)[0]
         rest = buf[4:]
         if not (n * 4 < len(rest)):

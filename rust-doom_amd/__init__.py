@@ -81,7 +81,7 @@ API_SYMBOLS = [
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
     'rdoom_built_counters', 'rdoom_built_lights_at', 'rdoom_built_start', 'rdoom_built_floor_centroids',
     'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_debug_set', 'rdoom_wad_walk', 'rdoom_wad_build_level_chained', 'rdoom_batch_render_objects', 'rdoom_level_num_objects', 'rdoom_batch_enable_primitive_ids',
-    'rdoom_wad_timings', 'rdoom_built_timings']
+    'rdoom_wad_timings', 'rdoom_built_timings', 'rdoom_pose_from_player']
 
 _lib = None
 
@@ -154,6 +154,16 @@ def pose_look(eye, yaw, pitch, width, height, time=0.0):
     e = (ctypes.c_float * 3)(*[float(x) for x in eye])
     _check(lib().rdoom_pose_look(e, ctypes.c_float(yaw), ctypes.c_float(pitch), int(width), int(height),
                                  ctypes.c_float(time), pose.ctypes.data_as(ctypes.c_void_p)))
+    return pose[0]
+
+
+def pose_from_player(pos, yaw, pitch, width, height, time=0.0):
+    """rdoom_pose_from_player: the same camera in the reference's own binary32 arithmetic (Decomposed / Quaternion of cgmath);
+    `pos` is the player's position -- the camera height (0.12) is added by the helper."""
+    pose = np.zeros(1, POSE)
+    e = (ctypes.c_float * 3)(*[float(x) for x in pos])
+    _check(lib().rdoom_pose_from_player(e, ctypes.c_float(yaw), ctypes.c_float(pitch), int(width), int(height),
+                                        ctypes.c_float(time), pose.ctypes.data_as(ctypes.c_void_p)))
     return pose[0]
 
 

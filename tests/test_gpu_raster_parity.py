@@ -20,8 +20,10 @@ def sweep_poses(lv, n, width, height, seed=7, time=0.0):
     poses = np.zeros(n, rd.POSE)
     sp = np.array([float(x) for x in lv.start_pos])
     for i in range(n):
-        if i == 0:
-            eye, yaw, pitch = sp + [0, 0.12, 0], float(lv.start_yaw), 1e-8
+        if i == 0:  # the reference's spawn view in the reference's own arithmetic (rdoom_pose_from_player)
+            p0 = rd.pose_from_player(sp, float(lv.start_yaw), 1e-8, width, height, time)
+            poses[0]['modelview'], poses[0]['projection'], poses[0]['time'] = p0['modelview'], p0['projection'], time
+            continue
         else:
             c = cents[rng.randint(len(cents))]
             eye = np.array([c[0] + rng.uniform(-0.3, 0.3), c[1] + rng.uniform(0.2, 0.6), c[2] + rng.uniform(-0.3, 0.3)])

@@ -32,8 +32,7 @@ LEVEL_LUMPS = ['THINGS', 'LINEDEFS', 'SIDEDEFS', 'VERTEXES', 'SEGS', 'SSECTORS',
 RECORD = dict(THINGS=10, LINEDEFS=14, SIDEDEFS=30, VERTEXES=4, SEGS=12, SSECTORS=4, NODES=28, SECTORS=26)
 
 
-@pytest.fixture(scope='session')
-def driver():
+def _build_driver_locked():
     host = os.path.join(ROOT, 'rust-doom_amd', 'csrc', 'host')
     srcs = sorted(glob.glob(os.path.join(host, '*.cpp'))) + [os.path.join(HERE, 'sanitize', 'host_driver.cpp')]
     deps = srcs + glob.glob(os.path.join(host, '*.hpp')) + [os.path.join(ROOT, 'include', 'rdoom.h'),
@@ -47,6 +46,11 @@ def driver():
     finally:
         fcntl.flock(lock, fcntl.LOCK_UN)
         lock.close()
+
+
+@pytest.fixture(scope='session')
+def driver():
+    return _build_driver_locked()
 
 
 def _build_driver(host, srcs, deps):

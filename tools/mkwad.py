@@ -161,7 +161,7 @@ def tex_pattern(kind, w, h, ramp, rng):
     return (ramp * 16 + shade).astype(np.int16)
 
 
-def make_graphics(rng):
+def make_graphics(rng, shapes=False):
     patches = {}  # name -> int16 [h][w]
 
     def patch(name, kind, w, h, ramp):
@@ -260,7 +260,31 @@ def make_graphics(rng):
     sprite('TRE1A0', 56, 76, 5, 'tri')
     sprite('GOR1A0', 20, 68, 1, 'column')
     sprite('CANDA1', 8, 15, 7, 'ellipse')      # only the ..1 rotation exists (sprite1 lookup path)
-    return patches, pnames, textures, flats, sprites
+    textures2 = []
+    if shapes:
+        # Lump shapes real IWADs have and the nine default levels do not:
+        #  * sprite lumps with paired rotations (eight-character names: wad/src/tex.rs:475-497 inserts every lump between
+        #    S_START and S_END under its own name), a family without an ..A0 lump (the decor looks ..A0 up, then ..A1,
+        #    wad/src/visitor.rs:1071-1083);
+        for name, w, h in (('COLUA2A8', 18, 48), ('COLUA3A7', 16, 48), ('COLUA4A6', 14, 48), ('COLUA5', 18, 48),
+                           ('POSSA1', 38, 56), ('POSSA2A8', 34, 56), ('POSSA3A7', 30, 55), ('POSSA4A6', 26, 56), ('POSSA5', 36, 54),
+                           ('POSSB1', 38, 56)):
+            sprite(name, w, h, 4 + len(sprites) % 9, 'ellipse' if name.startswith('POSS') else 'column')
+        #  * textures of three and more overlapping patches, transparent posts over opaque ones, the FIRST patch with holes
+        #    (blitted with ignore_transparency: its holes stay holes, wad/src/tex.rs:570, wad/src/image.rs:171-252), patches
+        #    hanging over every edge of the texture;
+        textures += [
+            T('OVERLAP3', 128, 128, [(0, 0, 'WALL01_1'), (20, 10, 'GRATE1'), (40, 30, 'DECAL1'), (-10, 100, 'GRATE1'),
+                                     (100, -20, 'DECAL1'), (90, 90, 'STEP1')]),
+            T('GRATEMIX', 64, 128, [(0, 0, 'GRATE1'), (8, 8, 'STEP1'), (30, 60, 'DECAL1'), (-40, -40, 'WALL03_1')]),
+        ]
+        #  * a TEXTURE2 lump next to TEXTURE1 (wad/src/tex.rs:71-88, 356), one of its textures only there, one re-defining
+        #    a TEXTURE1 name (IndexMap::insert: the later definition replaces the image, tex.rs:590).
+        textures2 = [
+            T('T2ONLY', 128, 72, [(0, 0, 'WALL02_1'), (64, 0, 'WALL03_1'), (32, 20, 'SW1S0')]),
+            T('BROWN1', 64, 128, [(0, 0, 'WALL02_1'), (0, 64, 'STEP1'), (32, 64, 'STEP2')]),
+        ]
+    return patches, pnames, textures, flats, sprites, textures2
 
 
 # --------------------------------------------------------------------------------------
@@ -913,15 +937,7 @@ def level_lumps(L, rng):
     return lumps, stats
 
 
-def build_wad(seed=1993, verbose=False, specs=None):
-    """specs (optional): list of (level name, ('gen', seed, grid, rooms) | ('kat',)) replacing the nine default levels."""
-    rng = Rng(seed)
-    pals = make_playpal()
-    cmaps = make_colormap(pals[0])
-    patches, pnames, textures, flats, sprites = make_graphics(rng)
-    lumps = [('PLAYPAL', b''.join(p.tobytes() for p in pals)),
-             ('COLORMAP', b''.join(c.tobytes() for c in cmaps))]
-    # TEXTURE1
+def texture_lump(textures):
     body, offs = b'', []
     base = 4 + 4 * len(textures)
     for (name, w, h, prefs) in textures:
@@ -929,25 +945,53 @@ def build_wad(seed=1993, verbose=False, specs=None):
         body += struct.pack('<8sIHHIH', name8(name), 0, w, h, 0, len(prefs))
         for (ox, oy, pi) in prefs:
             body += struct.pack('<hhHHH', ox, oy, pi, 1, 0)
-    lumps.append(('TEXTURE1', struct.pack('<I', len(textures)) + b''.join(struct.pack('<I', o) for o in offs) + body))
+    return struct.pack('<I', len(textures)) + b''.join(struct.pack('<I', o) for o in offs) + body
+
+
+def build_wad(seed=1993, verbose=False, specs=None, shapes=False):
+    """specs (optional): list of (level name, ('gen', seed, grid, rooms) | ('kat',)) replacing the nine default levels.
+    shapes: the lump shapes of real IWADs the default file lacks -- TEXTURE2, duplicated lump names (the LAST one is the
+    one a name finds: wad/src/archive.rs:85), sprite lumps with paired rotations, textures of many overlapping patches;
+    the levels then use the extra textures and things (the default IWAD, its levels and digests are unchanged)."""
+    global WALLS, DECOR_TYPES
+    rng = Rng(seed)
+    pals = make_playpal()
+    cmaps = make_colormap(pals[0])
+    patches, pnames, textures, flats, sprites, textures2 = make_graphics(rng, shapes)
+    lumps = [('PLAYPAL', b''.join(p.tobytes() for p in pals)),
+             ('COLORMAP', b''.join(c.tobytes() for c in cmaps))]
+    lumps.append(('TEXTURE1', texture_lump(textures)))
+    if textures2:
+        lumps.append(('TEXTURE2', texture_lump(textures2)))
     lumps.append(('PNAMES', struct.pack('<I', len(pnames)) + b''.join(name8(n) for n in pnames)))
+    saved = WALLS, DECOR_TYPES
+    if shapes:
+        WALLS = WALLS + ['OVERLAP3', 'GRATEMIX', 'T2ONLY']
+        DECOR_TYPES = DECOR_TYPES + [3004, 3004]
     stats = {}
     specs = specs or [('E1M1', ('gen', seed * 7 + 1, 52, 14)), ('E1M2', ('kat',)), ('E1M3', ('gen', seed * 7 + 3, 40, 9)),
              ('E1M4', ('gen', seed * 7 + 4, 44, 11)), ('E1M5', ('gen', seed * 7 + 5, 48, 12)),
              ('E1M6', ('gen', seed * 7 + 6, 56, 16)), ('E1M7', ('gen', seed * 7 + 7, 36, 8)),
              ('E1M8', ('gen', seed * 7 + 8, 60, 18)), ('E1M9', ('gen', seed * 7 + 9, 42, 10))]
-    for name, spec in specs:
-        L = kat_level() if spec[0] == 'kat' else gen_level(spec[1], spec[2], spec[3])
-        ll, st = level_lumps(L, Rng(seed + len(lumps)))
-        stats[name] = st
-        lumps.append((name, b''))
-        lumps.extend(ll)
+    try:
+        for name, spec in specs:
+            L = kat_level() if spec[0] == 'kat' else gen_level(spec[1], spec[2], spec[3])
+            ll, st = level_lumps(L, Rng(seed + len(lumps)))
+            stats[name] = st
+            lumps.append((name, b''))
+            lumps.extend(ll)
+    finally:
+        WALLS, DECOR_TYPES = saved
     lumps.append(('P_START', b''))
     for n, pix in patches.items():
+        if shapes and n in ('WALL02_1', 'STEP1'):   # a decoy under the same name FIRST: the name must find the later lump
+            lumps.append((n, encode_picture(np.full_like(pix, 251))))
         lumps.append((n, encode_picture(pix)))
     lumps.append(('P_END', b''))
     lumps.append(('F_START', b''))
     for n, pix in flats.items():
+        if shapes and n in ('FLAT14', 'FLOOR4_8'):  # likewise for flats (read in directory order into a map: the later one stays)
+            lumps.append((n, np.full(4096, 176, np.uint8).tobytes()))
         lumps.append((n, pix.tobytes()))
     lumps.append(('F_END', b''))
     lumps.append(('S_START', b''))
