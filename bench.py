@@ -126,7 +126,7 @@ OTHER_WORKLOADS = (   # BASELINE configs 2 / 4 / 5 (and the 4K frame) in short: 
 )
 
 
-def quick_line(rd, torch, sharding, wad, spec, streams, steps=5, warmup=1):
+def quick_line(rd, torch, sharding, wad, spec, streams, steps=8, warmup=2):
     """One short measurement of another workload, timed like the headline: the poses of every level as `streams` sub-batches on
     `streams` HIP streams (value), then as ONE batch on one stream for the per-kernel times."""
     w, h, n = spec['width'], spec['height'], spec['poses']

@@ -277,7 +277,8 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
     if (table_one) {
       id0 = tq;
       uniform = true;
-    } else if (tl != NONE) {  // (per lane: my quadrant has an entry, the other one has another or none)
+    } else if ((tl != NONE) & (debug_leak_mod == 0u)) {  // (per lane: my quadrant has an entry, the other one has another or none;
+                                                         // under leak_mod every pixel goes through its visibility word: all are there)
       id0 = tl;
       uniform = true;
     } else if (VIS16) {

@@ -13,18 +13,18 @@ export TMPDIR=/tmp
 ROOT=$PWD
 cd /tmp
 # (a) --streams 1: every kernel alone on the GPU, one launch per step -- the per-kernel accounting (rNN_kernel_stats.csv)
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o r --output-format csv -- python $ROOT/bench.py --streams 1 > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o r --output-format csv -- python $ROOT/bench.py --streams 1 --other off > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
 echo "stats (--streams 1) rc=$?"
 # (b) the default command as it is (two half-batches on two streams, then its single-stream pass): launches are half-batches,
 #     those of the timed region overlap (rNN_kernel_stats_default.csv + the kernel trace for tools/profile_collect.py)
-rocprofv3 --kernel-trace --stats -d $OUT/stats_default -o r --output-format csv -- python $ROOT/bench.py > $OUT/bench_profiled_default.json 2> $OUT/bench_profiled_default.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats_default -o r --output-format csv -- python $ROOT/bench.py --other off > $OUT/bench_profiled_default.json 2> $OUT/bench_profiled_default.err
 echo "stats (default) rc=$?"
 i=0
 for CTRS in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
             "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/pmc$i -o p --output-format csv -- python $ROOT/bench.py --streams 1 --steps 1 --warmup 1 --cpu-sample 0 > $OUT/pmc$i.log 2>&1
+  rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/pmc$i -o p --output-format csv -- python $ROOT/bench.py --streams 1 --steps 1 --warmup 1 --cpu-sample 0 --other off > $OUT/pmc$i.log 2>&1
   echo "pmc pass $i rc=$?"
 done
 cd $ROOT
@@ -34,7 +34,7 @@ tail -1 $OUT/bench_plain.json
 for ARGS in "--width 3840 --height 2160 --poses 256" "--width 1280 --height 720 --poses 2048" "--width 320 --height 200 --poses 8192" \
             "--big" "--big --width 3840 --height 2160 --poses 256 --time-varying" "--levels 0-8 --poses 512" \
             "--streams 1" "--streams 3" "--gpus 2" "--gpus 2 --scaling strong"; do
-  python bench.py $ARGS --steps 10 --warmup 2 --cpu-sample 0 2>/dev/null | grep '^{' | tail -1 >> $OUT/bench_other.jsonl
+  python bench.py $ARGS --steps 10 --warmup 2 --cpu-sample 0 --other off 2>/dev/null | grep '^{' | tail -1 >> $OUT/bench_other.jsonl
 done
 wc -l $OUT/bench_other.jsonl
 # 4. issue-slot / occupancy counters of the hot kernels on the final device sources
