@@ -7,7 +7,8 @@ from concurrent.futures import ThreadPoolExecutor
 import conftest  # noqa
 import rust_doom_amd as rd
 from oracle import raster, wad_oracle
-from util import META_PATH, ensure_big_wad, reference_projection, view_matrix
+from util import META_PATH, apply_stress_hooks, ensure_big_wad, reference_projection, render_checked, view_matrix
+print('# hooks:', ' '.join(apply_stress_hooks()))
 lv = wad_oracle.build_level(ensure_big_wad(), META_PATH, 0)
 rng = np.random.RandomState(123)
 tri = lv.static_vertices['a_pos'][lv.static_indices.reshape(-1, 3)].mean(1)
@@ -19,9 +20,9 @@ for (w, h, n) in [(640, 400, 160), (1920, 1080, 24)]:
         t = float(rng.choice([0.0, rng.uniform(0, 30)]))
         poses[i]['modelview'], poses[i]['projection'], poses[i]['time'] = view_matrix(eye, rng.uniform(0, 2 * np.pi), rng.uniform(-1.2, 1.2)), reference_projection(w, h), t
         lights[i] = lv.lights.fill_buffer_at(t)
-    batch = rd.Batch(rd.DeviceLevel(lv), w, h, n); batch.enable_primitive_ids()
-    batch.render(poses, lights)
-    fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+    batch = rd.Batch(rd.DeviceLevel(lv), w, h, n)
+    fb_plain, fb, prim = render_checked(batch, poses, lights)  # after a dirtying render; without and with primitive ids
+    assert np.array_equal(fb_plain, fb)
     ro = raster.RasterOracle(lv)
     def check(i):
         ofb, oprim = ro.render(poses[i]['modelview'], poses[i]['projection'], float(poses[i]['time']), lights[i], w, h, want_prim=True)

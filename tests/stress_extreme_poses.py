@@ -15,6 +15,10 @@ from util import META_PATH, ensure_wad, reference_projection, view_matrix  # noq
 
 
 def main():
+    from util import apply_stress_hooks
+    hooks = apply_stress_hooks()
+    if hooks:
+        print('# hooks:', ' '.join(hooks))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 9)
     total_bad = 0
@@ -44,9 +48,9 @@ def main():
             poses[i]['projection'], poses[i]['time'] = reference_projection(w, h), t
             lights[i] = lv.lights.fill_buffer_at(t)
         batch = rd.Batch(rd.DeviceLevel(lv), w, h, n_here)
-        batch.enable_primitive_ids()
-        batch.render(poses, lights)
-        fb, prim = batch.read_framebuffer(), batch.read_primitive_ids()
+        from util import render_checked
+        fb_plain, fb, prim = render_checked(batch, poses, lights)  # after a dirtying render; without and with primitive ids
+        assert np.array_equal(fb_plain, fb)
         ro = raster.RasterOracle(lv)
 
         def check(i):

@@ -82,6 +82,10 @@ def render_mismatches(product, index, lv, n, rng, size):
 
 
 def main():
+    from util import apply_stress_hooks
+    hooks = apply_stress_hooks()
+    if hooks:
+        print('# hooks:', ' '.join(hooks))
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     cpu_only = '--cpu-only' in sys.argv
     n_seeds = int(args[0]) if len(args) > 0 else 8

@@ -16,6 +16,10 @@ from util import META_PATH, ensure_wad, reference_projection, view_matrix  # noq
 
 
 def main():
+    from util import apply_stress_hooks
+    hooks = apply_stress_hooks()
+    if hooks:
+        print('# hooks:', ' '.join(hooks))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 48
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.RandomState(seed)

@@ -100,3 +100,14 @@ def render_checked(batch, poses, lights, want_prim=True, **kw):
     batch.render(other, olights, **dirty_kw)
     batch.render(poses, lights, **kw)
     return fb_plain, batch.read_framebuffer(), batch.read_primitive_ids()
+
+
+def apply_stress_hooks():
+    """hand-run stress scripts: RDOOM_STRESS_HOOKS="qpath=1 frag_bw=2" sets rdoom_debug_set hooks (equivalent paths: same images)
+    before anything renders -- the library itself never reads the environment"""
+    import rust_doom_amd as rd
+    hooks = os.environ.get('RDOOM_STRESS_HOOKS', '').split()
+    for item in hooks:
+        name, _, value = item.partition('=')
+        rd.debug_set(name, int(value or 1))
+    return hooks

@@ -9,6 +9,13 @@ TAG=${1:-r03}
   python tests/stress_extreme_poses.py 256 41
   python tests/stress_extreme_poses.py 256 42
   python tests/stress_big_level.py
+  # the same slices through the whole-quadrant fragment kernel (off by default: the qpath hook)
+  RDOOM_STRESS_HOOKS="qpath=1" python tests/stress_parity.py 48 36
+  RDOOM_STRESS_HOOKS="qpath=1" python tests/stress_parity.py 16 37 1920 1080
+  RDOOM_STRESS_HOOKS="qpath=1" python tests/stress_extreme_poses.py 128 43
+  RDOOM_STRESS_HOOKS="qpath=1" python tests/stress_big_level.py
+  python tests/stress_other_seeds.py ${SEEDS:-60} 7000 16
+  RDOOM_STRESS_HOOKS="qpath=1" python tests/stress_other_seeds.py 30 8000 16
 } > gpurun_out/${TAG}_stress.txt 2>&1
 tail -3 gpurun_out/${TAG}_stress.txt
 grep -c " ok" gpurun_out/${TAG}_stress.txt; grep -c MISMATCH gpurun_out/${TAG}_stress.txt
