@@ -133,10 +133,26 @@ def other_seed_wad(seed):
     return path
 
 
+def shapes_wad():
+    """the IWAD with the lump shapes real files have (TEXTURE2, duplicated names, MAPxx, paired-rotation sprites, textures of many
+    overlapping patches: tests/test_iwad_shapes.py, tests/golden/make_golden_shapes.py)"""
+    import tempfile
+    sys.path.insert(0, GOLDEN)
+    from make_golden_shapes import build_shapes_wad
+    path = os.path.join(tempfile.gettempdir(), 'rdoom_shapes_gl.wad')
+    if not os.path.exists(path):
+        tmp = '%s.%d.tmp' % (path, os.getpid())
+        build_shapes_wad(tmp)
+        os.replace(tmp, path)
+    return path
+
+
 def wad_of(key):
-    """level key -> (IWAD path, level index): an index of the synthetic IWAD, 'big', or 'seed<S>:<index>'"""
+    """level key -> (IWAD path, level index): an index of the synthetic IWAD, 'big', 'seed<S>:<index>' or 'shapes:<index>'"""
     if key == 'big':
         return ensure_big_wad(), 0
+    if isinstance(key, str) and key.startswith('shapes:'):
+        return shapes_wad(), int(key[7:])
     if isinstance(key, str) and key.startswith('seed'):
         seed, index = key[4:].split(':')
         return other_seed_wad(int(seed)), int(index)
@@ -178,6 +194,11 @@ def extended_frames():
             key = 'seed%d:%d' % (seed, index)
             out += [('seed%d_L%d_sweep%d_t%.1f_640' % (seed, index, i, t), key, 640, 400, sweep_pose(key, 640, 400, i, time=t), None)
                     for i, t in ((11, 0.0), (523, 5.3))]
+    # the IWAD with the lump shapes of real files: TEXTURE2's textures, many-patch textures with holes, sprites without an ..A0 lump
+    for index in range(3):
+        key = 'shapes:%d' % index
+        out += [('shapes_L%d_sweep%d_t%.1f_640' % (index, i, t), key, 640, 400, sweep_pose(key, 640, 400, i, time=t), None)
+                for i, t in ((7, 0.0), (301, 4.1), (655, 0.0))]
     return out
 
 

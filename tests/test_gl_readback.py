@@ -74,7 +74,7 @@ def mismatch_counts(lv, key, fb, prim):
 def test_extended_census_is_clean_and_bounded():
     tot = CENSUS['extended_total']
     assert tot['other'] == 0 and all(f['other'] == 0 for f in CENSUS['extended'].values())
-    assert tot['pixels'] >= 135_000_000 and len(CENSUS['extended']) >= 149
+    assert tot['pixels'] >= 138_000_000 and len(CENSUS['extended']) >= 158
     assert tot['mismatch'] <= MAX_MISMATCH_TOTAL * tot['pixels'], tot
     assert tot['winner_mismatch'] <= MAX_WINNER_MISMATCH_TOTAL * tot['pixels'], tot
     for k, f in CENSUS['extended'].items():
@@ -83,7 +83,8 @@ def test_extended_census_is_clean_and_bounded():
         assert f['mismatch'] - f['depth tie'] <= MAX_MISMATCH_FRAME * f['pixels'], (k, f)
         assert sum(f[c] for c in gl_census.CLASSES) == f['mismatch'], k
     assert sum(1 for f in CENSUS['extended'].values() if f['width'] == 1920) >= 32
-    assert {f['level'] for f in CENSUS['extended'].values()} == set(range(9)) | {'big'} | {'seed%d:%d' % (s, i) for s in gen.OTHER_SEEDS for i in range(3)}
+    assert {f['level'] for f in CENSUS['extended'].values()} == (set(range(9)) | {'big'} | {'seed%d:%d' % (s, i) for s in gen.OTHER_SEEDS for i in range(3)} |
+                                                                 {'shapes:%d' % i for i in range(3)})
     assert sum(1 for f in CENSUS['extended'].values() if f['width'] == 3840) >= 4
     assert sum(1 for f in CENSUS['extended'].values() if f['objects_seed'] is not None and f['time'] > 0) >= 27
 
@@ -147,7 +148,7 @@ def test_swiftshader_runs_the_reference_shaders(oracle_levels, key):
 
 @pytest.mark.skipif(not gl_readback.available(), reason='needs SwiftShader and the reference checkout (/root/reference)')
 @pytest.mark.parametrize('key', ['L0_bench624_1080p', 'L5_sweep128_640', 'L3_sweep424_t12.1_objects_640', 'L7_sweep808_t34.5_objects_640',
-                                 'seed4242_L0_sweep523_t5.3_640'])
+                                 'seed4242_L0_sweep523_t5.3_640', 'shapes_L1_sweep301_t4.1_640', 'shapes_L2_sweep7_t0.0_640'])
 def test_swiftshader_extended_census(key):
     """regenerates the counts of extended frames (nothing stored but the counts) from the reference's shader files"""
     c = CENSUS['extended'][key]
