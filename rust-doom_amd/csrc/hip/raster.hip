@@ -22,6 +22,9 @@ namespace {
 // time go?  Every mark waits for the wave's outstanding memory operations, reads the shader clock (s_memtime) and
 // charges the cycles since the previous mark to a section; lane 0 adds the wave's sums to g_raster_t at the end.  The
 // waits serialise what would overlap and the reads cost cycles themselves: the SHARES are the result, not the total.
+#ifdef RDOOM_CENSUS_TWO
+__device__ unsigned long long g_raster_census[64];
+#endif
 #ifdef RDOOM_RASTER_TIMERS
 __device__ unsigned long long g_raster_t[16];
 __device__ __forceinline__ unsigned long long rt_now() {
@@ -289,6 +292,9 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __shared__ uint32_t wq[RASTER_WAVES][64];
   __shared__ uint4 wrec[RASTER_WAVES][64][4];  // per wave: 15 words of each of the 64 gathered raster records
+  // per entry: a sign-blind hash of each edge's three coefficients (a shared edge has exactly negated coefficients in the two
+  // triangles, S3) and, per quadrant, "covers the quadrant but for edge k" (bit 4 k + q) -- the two-entry shortcut below
+  __shared__ uint4 whash[RASTER_WAVES][64];
   // grid = (8 tiles_x, tiles_y, pose groups of 8): workgroups are dispatched x-fastest and dealt to the eight XCDs in turn,
   // so blockIdx.x & 7 is the XCD and all tiles of a pose land on one of them; no division is needed to find (pose, tile)
   static_assert(RASTER_WAVES == 1, "the 3-D grid maps one tile to one workgroup");
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
         const float za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
         const float wa = __uint_as_float(c3.x), wb = __uint_as_float(c3.y), wc = __uint_as_float(c3.z);
         const int x0 = (int)(c3.w & 0xFFFFu), y0 = (int)(c3.w >> 16), x1 = (int)(c4.x & 0xFFFFu), y1 = (int)(c4.x >> 16);
-        uint32_t dn[4];
+        uint32_t dn[4], covx = 0u;
 #pragma unroll
         for (int qi = 0; qi < 4; qi++) {
           const int rx0 = tx0 + (qi & 1) * 32, ry0 = ty0 + (qi >> 1) * 32;
@@ -392,10 +398,19 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
 #else
           const int qx1 = rx0 + 31, qy1 = ry0 + 31;
 #endif
-          const bool cov = (n0 > 0.0f) & (n1 > 0.0f) & (n2 > 0.0f) & (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) &
-                           (x0 <= rx0) & (x1 >= qx1) & (y0 <= ry0) & (y1 >= qy1) &
-                           ((c4.y & RASTER_MASKED_INTERIOR) == 0u);
+          const bool common = (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) & (x0 <= rx0) & (x1 >= qx1) & (y0 <= ry0) & (y1 >= qy1) &
+                              ((c4.y & RASTER_MASKED_INTERIOR) == 0u);
+          const bool p0 = n0 > 0.0f, p1 = n1 > 0.0f, p2 = n2 > 0.0f;
+          const bool cov = common & p0 & p1 & p2;
           myqb |= (cov && !no_cover) ? (16u << qi) : 0u;  // no_cover: test hook
+          covx |= ((common & p1 & p2) ? (1u << qi) : 0u) | ((common & p0 & p2) ? (16u << qi) : 0u) | ((common & p0 & p1) ? (256u << qi) : 0u);
+        }
+        {
+          auto mag = [](uint32_t v) { return v & 0x7FFFFFFFu; };
+          auto edge_hash = [&](uint32_t a, uint32_t b, uint32_t c) {
+            return mag(a) ^ __builtin_amdgcn_alignbit(mag(b), mag(b), 21) ^ __builtin_amdgcn_alignbit(mag(c), mag(c), 11);
+          };
+          whash[wave][lane] = make_uint4(edge_hash(c0.x, c0.y, c0.z), edge_hash(c0.w, c1.x, c1.y), edge_hash(c1.z, c1.w, c2.x), no_cover ? 0u : covx);
         }
         dnq0 = dn[0], dnq1 = dn[1], dnq2 = dn[2], dnq3 = dn[3];
         myrq = myrec | (myqb << 24);
@@ -526,6 +541,106 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
             continue;
           }
         }
+#ifndef RDOOM_NO_PAIR_SHORTCUT
+        // The two-entry shortcut.  A third of the quadrants that show more than one triangle show exactly TWO that share an edge
+        // -- the diagonal of a wall quad, a spoke of a floor fan (census with the oracle's winners: 9.6 % of all quadrants at
+        // 1080p).  Set-up gives a shared edge exactly negated coefficients in the two triangles (S3), so e_B(pixel) = -e_A(pixel)
+        // bit for bit and the tie flags of the two sides are complementary: every pixel lies inside exactly one of them as far
+        // as that edge is concerned.  When both triangles cover the quadrant but for that edge (their other edges, the depth
+        // range, 1/w and the bbox hold at the quadrant's corners -- the same corner arguments as the one-entry shortcut) and
+        // every other entry lies strictly behind the farther of their farthest depths, the winner of a pixel is decided by the
+        // sign of ONE edge function: no depth is evaluated, nothing is initialised.  A = the entry that is nearest over the
+        // quadrant, B = a touching entry one of whose edge hashes equals one of A's (verified exactly below).
+        const uint4 hA4 = whash[wave][s0];
+        const uint32_t cxA = ((uint32_t)__builtin_amdgcn_readfirstlane((int)hA4.w) >> q) & 0x111u;  // A covers but for edge 0 / 1 / 2: bits 0 / 4 / 8
+        if (cxA != 0u && __popcll(touch_s) >= 2) {  // (most quadrants that show several triangles leave here: no edge of A to share)
+          const uint4 hme = whash[wave][lane];
+          const uint32_t hA0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hA4.x), hA1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hA4.y),
+                         hA2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hA4.z);
+          const uint32_t cxm = (hme.w >> q) & 0x111u;
+          // bit 3 i + j: A's edge i and my edge j have equal hashes, and each of us covers the quadrant but for that edge
+          const bool m0 = (cxm & 1u) != 0u, m1 = (cxm & 16u) != 0u, m2 = (cxm & 256u) != 0u;
+          const bool A0 = (cxA & 1u) != 0u, A1 = (cxA & 16u) != 0u, A2 = (cxA & 256u) != 0u;
+          const uint32_t mm = (((hme.x == hA0) & m0 & A0) ? 1u : 0u) | (((hme.y == hA0) & m1 & A0) ? 2u : 0u) | (((hme.z == hA0) & m2 & A0) ? 4u : 0u) |
+                              (((hme.x == hA1) & m0 & A1) ? 8u : 0u) | (((hme.y == hA1) & m1 & A1) ? 16u : 0u) | (((hme.z == hA1) & m2 & A1) ? 32u : 0u) |
+                              (((hme.x == hA2) & m0 & A2) ? 64u : 0u) | (((hme.y == hA2) & m1 & A2) ? 128u : 0u) | (((hme.z == hA2) & m2 & A2) ? 256u : 0u);
+          unsigned long long cm = __ballot(mm != 0u) & touch_s & ~(1ull << s0);
+          bool paired = false;
+          while (cm != 0ull && !paired) {
+            const uint32_t sB = (uint32_t)__builtin_ctzll(cm);
+            cm &= cm - 1ull;
+            const uint32_t mB = (uint32_t)__builtin_amdgcn_readlane((int)mm, (int)sB);
+            const uint32_t ij = (uint32_t)__builtin_ctz(mB), ei = ij / 3u, ej = ij - ei * 3u;
+            // the two edges, exactly: words 3 k .. 3 k + 2 of the nine edge words (parked as words 0..7 and 12 of the record's slot)
+            const uint32_t *wa = reinterpret_cast<const uint32_t *>(wrec[wave][s0]), *wb = reinterpret_cast<const uint32_t *>(wrec[wave][sB]);
+            auto word = [](const uint32_t *w, uint32_t k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)w[k < 8u ? k : 12u]); };  // edge words
+            auto slot = [](const uint32_t *w, uint32_t k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)w[k]); };                  // any parked word
+            const uint32_t a0 = word(wa, 3u * ei), a1 = word(wa, 3u * ei + 1u), a2 = word(wa, 3u * ei + 2u);
+            const uint32_t b0 = word(wb, 3u * ej), b1 = word(wb, 3u * ej + 1u), b2 = word(wb, 3u * ej + 2u);
+            auto negated = [](uint32_t x, uint32_t y) { return ((x ^ y) == 0x80000000u) | (((x | y) << 1) == 0u); };  // y = -x, or both are zeros
+            const uint32_t fA = slot(wa, 14u), fB = slot(wb, 14u);  // flags: primitive id, tie bits 24..26 (slot word 14 = c4.y)
+            const bool tlA = ((fA >> (24u + ei)) & 1u) != 0u, tlB = ((fB >> (24u + ej)) & 1u) != 0u;
+            bool ok = negated(a0, b0) & negated(a1, b1) & negated(a2, b2) & (tlA != tlB);  // (the cover-but-for-this-edge bits are in mm)
+            if (!ok) continue;
+            const float ea = __uint_as_float(a0), eb = __uint_as_float(a1), ec = __uint_as_float(a2);
+            const float xl = (float)qx0 + 0.5f, xh = (float)qx0 + 31.5f, yl = (float)qy0 + 0.5f, yh = (float)qy0 + 31.5f;
+            // the shared edge function is finite at the four corners, hence (fmaf is monotone in each argument) at every pixel
+            const float tl_ = fmaf(eb, yl, ec), th_ = fmaf(eb, yh, ec);
+            const bool finite = ((__float_as_uint(fmaf(ea, xl, tl_)) & 0x7F800000u) != 0x7F800000u) & ((__float_as_uint(fmaf(ea, xh, tl_)) & 0x7F800000u) != 0x7F800000u) &
+                                ((__float_as_uint(fmaf(ea, xl, th_)) & 0x7F800000u) != 0x7F800000u) & ((__float_as_uint(fmaf(ea, xh, th_)) & 0x7F800000u) != 0x7F800000u);
+            // farthest depth of the two over the quadrant; everything else strictly behind it
+            auto far_of = [&](uint32_t sl) {
+              const float za = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpa, (int)sl)), zb = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpb, (int)sl)),
+                          zc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)zpc, (int)sl));
+              const float zf = fmaf(za, pos(za) ? xh : xl, fmaf(zb, pos(zb) ? yh : yl, zc));  // in [0, 1]: the entry's depth range holds over the quadrant
+              return __float2uint_rz(fmaf(zf, 16777215.0f, 0.5f));
+            };
+            const uint32_t dfar = max(far_of(s0), far_of(sB));
+            ok = finite & ((__ballot(dnq_s <= dfar) & touch_s & ~(1ull << s0) & ~(1ull << sB)) == 0ull);
+            if (!ok) continue;
+            paired = true;
+            const uint32_t rA = (uint32_t)__builtin_amdgcn_readlane((int)myrq, (int)s0) & 0xFFFFFFu, rB = (uint32_t)__builtin_amdgcn_readlane((int)myrq, (int)sB) & 0xFFFFFFu;
+            if (STATS) st[0] += (unsigned long long)__popcll(touch_s), st[8]++;
+            if (qtab && lane == 0) qtab[((size_t)pose * T + tile) * 4u + (uint32_t)q] = NONE;  // two records: not described
+            if (bx < width) {
+              const size_t o0 = ((size_t)pose * (size_t)height + (size_t)by) * (size_t)width + (size_t)bx;
+              const uint32_t pA = PRIM ? (fA & 0xFFFFFFu) : 0u, pB = PRIM ? (fB & 0xFFFFFFu) : 0u;
+#pragma unroll
+              for (int ry = 0; ry < 4; ry++) {
+                const float trow = fmaf(eb, pylo + (float)ry, ec);
+                uint32_t w[4];
+                bool in[4];
+#pragma unroll
+                for (int rx = 0; rx < 4; rx++) {
+                  const float e = fmaf(ea, pxlo + (float)rx, trow);  // R1 for A's side of the shared edge
+                  in[rx] = (e > 0.0f) | ((e == 0.0f) & tlA);
+                  w[rx] = in[rx] ? rA : rB;
+                }
+                if (by + ry < height) {
+                  const size_t o = o0 + (size_t)(ry * width);
+                  if (VIS16)
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(vis) + o) =
+                        make_uint2(__builtin_amdgcn_perm(w[1], w[0], 0x05040100u), __builtin_amdgcn_perm(w[3], w[2], 0x05040100u));
+                  else
+                    *reinterpret_cast<uint4 *>(vis + o) = make_uint4(w[0], w[1], w[2], w[3]);
+                  if (PRIM) *reinterpret_cast<uint4 *>(prim_out + o) = make_uint4(in[0] ? pA : pB, in[1] ? pA : pB, in[2] ? pA : pB, in[3] ? pA : pB);
+                }
+              }
+            }
+          }
+          if (paired) {
+            RT_MARK(4);
+            continue;
+          }
+#ifdef RDOOM_CENSUS_TWO  // census build only (tools/variant.sh rcensus raster -DRDOOM_CENSUS_TWO): what do the remaining full passes look like?
+          {
+            const uint32_t nt = min((uint32_t)__popcll(touch_s), 7u);
+            const uint32_t ncx = min((uint32_t)__popcll(__ballot(((hme.w >> q) & 0x111u) != 0u) & touch_s), 3u);   // entries that cover but for one edge
+            if (lane == 0) atomicAdd(&g_raster_census[nt * 4u + ncx], 1ull);
+          }
+#endif
+        }
+#endif
       }
     }
     RT_MARK(5);  // quadrant shortcut, not taken
@@ -714,6 +829,16 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
   hipLaunchKernelGGL(rk, dim3((uint32_t)tiles_x * 8u, (uint32_t)tiles_y, groups), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, dbg.no_cover ? 1u : 0u,
                      qtab, d_stats);
+#ifdef RDOOM_CENSUS_TWO
+  {
+    unsigned long long h[64], zero[64] = {};
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_raster_census), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raster_census), zero, sizeof zero);
+    fprintf(stderr, "[raster census] passes that reach the two-entry test with an edge of the nearest entry to share, by touching entries (rows 0..7+) x entries that cover but for one edge (0..3+):\n");
+    for (int t = 0; t < 8; t++) fprintf(stderr, "   %d: %llu %llu %llu %llu\n", t, h[4 * t], h[4 * t + 1], h[4 * t + 2], h[4 * t + 3]);
+  }
+#endif
 #ifdef RDOOM_RASTER_TIMERS
   {
     unsigned long long h[16], zero[16] = {};
@@ -736,10 +861,10 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
     const double waves = (double)groups * 8.0 * (double)(tiles_x * tiles_y) * 4.0;  // (pose, quadrant) passes
     fprintf(stderr,
             "[rdoom stats] per quadrant pass: queue %.1f  past quadrant early-z %.1f  quadrant-cover %.2f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"
-            "  general %.3f (lanes %.1f: masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | one-entry shortcut %.3f, one winner in the end %.3f\n",
+            "  general %.3f (lanes %.1f: masked %.1f, tie %.1f) | rejected: early-z %.2f, then geometry %.2f | one-entry shortcut %.3f, one winner in the end %.3f, two-entry shortcut %.4f (%llu of %.0f passes)\n",
             h[0] / waves, h[1] / waves, h[10] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
             h[4] ? (double)h[5] / h[4] : 0.0, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
-            h[6] ? (double)h[12] / h[6] : 0.0, h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, h[9] / waves, h[11] / waves);
+            h[6] ? (double)h[12] / h[6] : 0.0, h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, h[9] / waves, h[11] / waves, h[8] / waves, h[8], waves);
   }
   return RDOOM_OK;
 }
