@@ -49,6 +49,9 @@ __device__ unsigned long long g_frag_stats[16];
 #ifndef RDOOM_FRAG_MAGIC
 #define RDOOM_FRAG_MAGIC 0  // texel addresses through the round-down magic-number floor (0: four v_cvt_flr_i32_f32 per pixel pair)
 #endif
+#ifndef RDOOM_FRAG_ADDR2
+#define RDOOM_FRAG_ADDR2 1  // texel byte offsets from scaled coordinates (two and-s and an or per texel)
+#endif
 #ifndef RDOOM_FRAG_CHUNK
 #define RDOOM_FRAG_CHUNK 16
 #endif
@@ -335,6 +338,12 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
       const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
       const uint32_t base2 = base * 2u;  // byte offsets < 2^27: one 32-bit VGPR offset from the uniform base pointer
       const char *tb = reinterpret_cast<const char *>(texels);
+#if RDOOM_FRAG_ADDR2 && !RDOOM_FRAG_MAGIC
+      const uint32_t wm2a = wm << 1, hms = hm << (lw + 1u);
+      const float ysc = __uint_as_float((128u + lw) << 23);  // 2 W = 2^(lw + 1)
+      const float au2 = atlas_u * 2.0f, avs = atlas_v * ysc;
+      const char *tba = ONE ? tb + base2 : tb;  // (wave-uniform record: the store's base is scalar pointer arithmetic)
+#endif
 #if RDOOM_FRAG_MAGIC
       const uint32_t wm2 = wm << 1;
       // the store's base: with a wave-uniform record the pointer arithmetic is scalar; per-lane records keep a 32-bit offset
@@ -405,6 +414,17 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         const uint32_t o1 = ((__float_as_uint(fyb.y) & hm) << (lw + 1u)) | (__float_as_uint(fxb.y) & wm2);
         texel[2 * p] = (DBG & 2) ? (o0 & 255u) : *reinterpret_cast<const TexelWord *>(tb2 + (ONE ? o0 : o0 + lane_base2));
         texel[2 * p + 1] = (DBG & 2) ? (o1 & 255u) : *reinterpret_cast<const TexelWord *>(tb2 + (ONE ? o1 : o1 + lane_base2));
+#elif RDOOM_FRAG_ADDR2
+        // the texel's BYTE offset from two and-s and an or (as fragment_quadrant_kernel forms it): the atlas origin is added
+        // with fma(r, 2, 2 atlas_u) = 2 RN(r + atlas_u) and fma(r, 2 W, 2 W atlas_v) = 2 W RN(r + atlas_v) -- scaling by a power
+        // of two commutes with the rounding --, floor of those is 2 floor(x) + {0, 1} and 2 W floor(y) + {0 .. 2 W - 1}, and the
+        // masks (W - 1) << 1 and (H - 1) << (log2 W + 1) drop exactly the surplus bits (coordinates are >= 0)
+        (void)ux, (void)uy;
+        const f32x2 ux2 = pk_fma(rx, splat(2.0f), splat(au2)), uys = pk_fma(ry, splat(ysc), splat(avs));
+        const uint32_t b0 = ((uint32_t)cvt_floor_i32(uys.x) & hms) | ((uint32_t)cvt_floor_i32(ux2.x) & wm2a);
+        const uint32_t b1 = ((uint32_t)cvt_floor_i32(uys.y) & hms) | ((uint32_t)cvt_floor_i32(ux2.y) & wm2a);
+        texel[2 * p] = (DBG & 2) ? (b0 & 255u) : *reinterpret_cast<const TexelWord *>(tba + (ONE ? b0 : b0 + base2));
+        texel[2 * p + 1] = (DBG & 2) ? (b1 & 255u) : *reinterpret_cast<const TexelWord *>(tba + (ONE ? b1 : b1 + base2));
 #else
         const uint32_t o0 = (((uint32_t)cvt_floor_i32(uy.x) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.x) & wm);
         const uint32_t o1 = (((uint32_t)cvt_floor_i32(uy.y) & hm) << lw) | ((uint32_t)cvt_floor_i32(ux.y) & wm);
@@ -431,6 +451,13 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
       };
       const f32x2 rf_ends = rows_of(f32x2{w_first, w_last});
       uint32_t ci[NPX];  // COLORMAP index = row * 256 + texel
+#ifdef RDOOM_FRAG_STATS
+      {  // census: how often does the per-pixel row evaluation below run (it runs for the whole wave when one run needs it)?
+        const unsigned long long dm = __ballot(rf_ends.x != rf_ends.y);
+        if (lane == 0u) atomicAdd(&g_frag_stats[14], 1ull);
+        if (lane == 0u && dm) atomicAdd(&g_frag_stats[15], 1ull), atomicAdd(&g_frag_stats[2], (unsigned long long)__popcll(dm));
+      }
+#endif
       if (rf_ends.x == rf_ends.y) {
         const uint32_t r8 = (uint32_t)(int)rf_ends.x << 8;
 #pragma unroll
@@ -1012,6 +1039,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_frag_stats), sizeof h);
     fprintf(stderr, "[frag stats] quadrants in the frame: undescribed %llu, described %llu (not shaded by the quadrant kernel: sky / decor / ineligible sizes %llu, non-power-of-two size %llu, masked texture %llu) | blocks of fragment_kernel: walked %llu, skipped %llu, walked with one handled half %llu\n",
             h[3], h[4], h[5], h[6], h[7], h[0], h[1], h[2]);
+    fprintf(stderr, "[frag stats] packed-body invocations (waves) %llu, of which with some run whose COLORMAP rows differ at its ends %llu (%.1f %%; such runs %llu)\n", h[14], h[15], h[14] ? 100.0 * h[15] / h[14] : 0.0, h[2]);
     fprintf(stderr, "[frag stats] runs %llu: to the general body %llu (%.2f %%): mixed %llu, rw out of range %llu, mod uncertified %llu, transparent texel %llu, other (decor, ineligible sizes) %llu\n", h[8], h[9], 100.0 * h[9] / h[8], h[10], h[11], h[12], h[13], h[9] - h[10] - h[11] - h[12] - h[13]);
   }
 #endif
