@@ -30,6 +30,14 @@ namespace {
 // rank).  Order only affects early-z efficiency: the winner is order-independent.  If a pose needs more than
 // entry_cap entries (or the frame has more than MAX_TILES tiles) its overflow flag is set and the
 // rasteriser scans the sorted list instead.
+// SPLIT LISTS.  A tile whose list is longer than one batch of the rasteriser (LONG_LIST = 64 entries, one per lane) is far
+// geometry -- small triangles that touch one 32 x 32 quadrant each -- and the rasteriser, which gathers a tile's list once
+// for its four quadrants when it fits the lanes, would gather ALL of it again for every quadrant (at 320 x 200 a quarter of
+// the tiles hold 78 % of the entries this way; on the large level a tenth holds 76 %).  Such a tile gets one list PER
+// QUADRANT instead (an entry that touches several quadrants is in each of their lists): header word y carries
+// TILE_SPLIT, word x points at eight words (first entry, count) x 4 in the entry array, the four lists follow.  The
+// rasteriser treats each as the list of a tile that consists of that quadrant: most fit one batch again (one gather, the
+// shortcuts apply), the rest re-gathers only its own entries.
 // =================================================================================================
 
 // Inclusive prefix sum over the workgroup: shuffles inside a wave, the wave totals through LDS (two barriers; tmp[w] ends
@@ -65,10 +73,11 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
                                                           const uint32_t *__restrict__ counts, uint32_t cap,
                                                           int tiles_x, int tiles_y, uint2 *__restrict__ tile_hdr,
                                                           uint32_t *__restrict__ entries, uint32_t entry_cap,
-                                                          uint2 *__restrict__ hits, uint32_t *__restrict__ overflow) {
+                                                          uint2 *__restrict__ hits, uint32_t *__restrict__ overflow,
+                                                          uint32_t split) {
   constexpr uint32_t BIN_CHUNK = BIN_THREADS;
   static_assert((1 << BIN_LOG2) == BIN_THREADS, "bin_kernel: BIN_LOG2");
-  extern __shared__ uint32_t bin_dyn[];  // tile_cnt[T], tile_off[T]
+  extern __shared__ unsigned long long bin_dyn[];  // split: qc[T] (64 bits per tile), then -- always -- tile_cnt[T] (entries per tile, later the fill pass's cursor)
   __shared__ uint4 coef[BIN_CHUNK][3];   // e[9], zp[3] of the staged triangles
   __shared__ uint2 bbox[BIN_CHUNK];
   __shared__ uint32_t trange[BIN_CHUNK];  // tile rectangle to visit: tx0 | ty0 << 8 | width << 16
@@ -82,19 +91,25 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
     if (tid == 0) overflow[pose] = 1u;
     return;
   }
-  uint32_t *tile_cnt = bin_dyn, *tile_off = bin_dyn + T;
+  // per-quadrant entry counts of every tile, four 16-bit fields in one 64-bit word -- one LDS atomic per pair found (a tile
+  // with more than 65 535 entries overflows the pose); for the fill pass the fields become the four lists' cursors
+  unsigned long long *qc = bin_dyn;
+  uint32_t *tile_cnt = reinterpret_cast<uint32_t *>(bin_dyn + (split ? T : 0u));
   const TriRec *prec = recs + (size_t)pose * cap;
   const uint4 *psorted = sorted + (size_t)pose * cap;
   uint2 *hdr = tile_hdr + (size_t)pose * T;
   uint32_t *pent = entries + (size_t)pose * entry_cap;
   uint2 *phits = hits + (size_t)pose * entry_cap;  // (entry, tile) of every pair that passed: the fill pass only scatters
   const uint32_t n = counts[pose];
-  for (uint32_t i = tid; i < T; i += BIN_THREADS) tile_cnt[i] = 0;
+  for (uint32_t i = tid; i < T; i += BIN_THREADS) {
+    tile_cnt[i] = 0;
+    if (split) qc[i] = 0ull;
+  }
   if (tid == 0) n_hits = 0;
   {
     for (uint32_t cbase = 0; cbase < n; cbase += BIN_CHUNK) {
       const uint32_t cn = min(BIN_CHUNK, n - cbase);
-      __syncthreads();  // previous round's readers of coef/pref are done (and tile_cnt / tile_off are ready)
+      __syncthreads();  // previous round's readers of coef/pref are done (and the tile counters are zeroed)
       uint32_t nt = 0;
       if ((uint32_t)tid < cn) {
         const uint4 ent = psorted[cbase + tid];  // (bb0, bb1, record index == cbase + tid, depth bucket)
@@ -149,33 +164,84 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
         if (qm) {
           const uint32_t tile = (uint32_t)((ty0 + ty) * tiles_x + tx0 + tx);
           atomicAdd(&tile_cnt[tile], 1u);
+          if (split)
+            atomicAdd(&qc[tile], (unsigned long long)((qm & 1u) | ((qm & 2u) << 15)) | ((unsigned long long)(((qm >> 2) & 1u) | ((qm & 8u) << 13)) << 32));
           const uint32_t k = atomicAdd(&n_hits, 1u);  // (a pose with more than entry_cap pairs overflows below)
           if (k < entry_cap) phits[k] = make_uint2((cbase + lo) | (qm << 28), tile);
         }
       }
     }
     __syncthreads();
-    // exclusive scan of tile_cnt -> tile_off (thread t owns T/512 consecutive tiles); headers out
+    // exclusive scan of the tiles' list sizes -> first entries (thread t owns T / BIN_THREADS consecutive tiles); headers out
     const uint32_t per = (T + BIN_THREADS - 1u) / BIN_THREADS, lo = min((uint32_t)tid * per, T), hi = min(lo + per, T);
+    auto quads_of = [&](uint32_t i, uint32_t (&c)[4]) {
+      const unsigned long long v = qc[i];
+      c[0] = (uint32_t)v & 0xFFFFu, c[1] = ((uint32_t)v >> 16), c[2] = (uint32_t)(v >> 32) & 0xFFFFu, c[3] = (uint32_t)(v >> 48);
+    };
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += tile_cnt[i];
+    int huge = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+      const uint32_t c = tile_cnt[i];
+      uint32_t size = c;
+      if (split && c > LONG_LIST) {
+        uint32_t qc[4];
+        quads_of(i, qc);
+        size = 8u + qc[0] + qc[1] + qc[2] + qc[3];
+        huge |= (c > 0xFFFFu) | (size > 0xFFFFu);  // (counts and cursors are 16-bit fields)
+      }
+      sum += size;
+    }
     const uint32_t incl_t = block_scan<BIN_THREADS>(sum, scan_tmp);
     const uint32_t total = scan_tmp[BIN_THREADS / 64 - 1];
+    // too many entries for the pose's share of the entry array (the pairs found, which the hits array holds, or the entries
+    // with the split lists' copies), or a 16-bit quadrant count that may have wrapped: the rasteriser scans the sorted list
+    const bool over = __syncthreads_or(huge) != 0 || total > entry_cap || n_hits > entry_cap;
+    if (tid == 0) overflow[pose] = over ? 1u : 0u;
+    if (over) return;  // uniform
     uint32_t run = incl_t - sum;
     for (uint32_t i = lo; i < hi; i++) {
-      tile_off[i] = run;
-      hdr[i] = make_uint2(run, tile_cnt[i]);
-      run += tile_cnt[i];
+      const uint32_t c = tile_cnt[i];
+      if (split && c > LONG_LIST) {
+        uint32_t qc[4];
+        quads_of(i, qc);
+        uint32_t o = run + 8u;
+        unsigned long long cursors = 0ull;  // each list's next free place, relative to the tile's first word
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          pent[run + 2u * (uint32_t)q] = o;
+          pent[run + 2u * (uint32_t)q + 1u] = qc[q];
+          cursors |= (unsigned long long)(o - run) << (16 * q);
+          o += qc[q];
+        }
+        hdr[i] = make_uint2(run, c | TILE_SPLIT);
+        tile_cnt[i] = run | TILE_SPLIT;
+        run = o;
+        bin_dyn[i] = cursors;
+      } else {
+        hdr[i] = make_uint2(run, c);
+        tile_cnt[i] = run;  // the fill pass's cursor
+        run += c;
+      }
     }
-    if (tid == 0) overflow[pose] = total > entry_cap ? 1u : 0u;
-    if (total > entry_cap) return;  // uniform
-    __syncthreads();
+    __syncthreads();  // cursors, and the split tiles' sub-headers (global memory written by this workgroup), are in place
     // fill: the pairs are read back in the order they were found (near to far up to a window of BIN_CHUNK triangles)
-    for (uint32_t k0 = 0; k0 < total; k0 += BIN_THREADS) {
+    const uint32_t found = n_hits;
+    for (uint32_t k0 = 0; k0 < found; k0 += BIN_THREADS) {
       const uint32_t k = k0 + (uint32_t)tid;
-      if (k < total) {
+      if (k < found) {
         const uint2 h = phits[k];
-        pent[atomicAdd(&tile_off[h.y], 1u)] = h.x;
+        const uint32_t cur = tile_cnt[h.y];
+        if (!(cur & TILE_SPLIT)) {
+          pent[atomicAdd(&tile_cnt[h.y], 1u)] = h.x;
+        } else {
+          // one copy per quadrant touched: ONE atomic advances the cursors of all of them and returns where each copy goes
+          const uint32_t base = cur & ~TILE_SPLIT, qm = h.x >> 28;
+          const unsigned long long inc = (unsigned long long)((qm & 1u) | ((qm & 2u) << 15)) | ((unsigned long long)(((qm >> 2) & 1u) | ((qm & 8u) << 13)) << 32);
+          const unsigned long long at = atomicAdd(&qc[h.y], inc);
+#pragma unroll
+          for (uint32_t q = 0; q < 4u; q++)
+            if ((qm >> q) & 1u) pent[base + ((uint32_t)(at >> (16u * q)) & 0xFFFFu)] = h.x;
+        }
       }
     }
   }
@@ -185,13 +251,13 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
 
 bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
                 uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
-                uint2 *hits, uint32_t *overflow) {
+                uint2 *hits, uint32_t *overflow, bool want_split, bool *used_split) {
   const uint32_t bin_tiles = std::min<uint32_t>((uint32_t)(tiles_x * tiles_y), MAX_TILES);
   const int bin_threads = rdoom::debug_options().bin_threads;
   auto bk = bin_threads == 512 ? bin_kernel<512, 9> : (bin_threads == 128 ? bin_kernel<128, 7> : bin_kernel<256, 8>);
   const int bt = bin_threads == 512 ? 512 : (bin_threads == 128 ? 128 : 256);
-  // LDS budget: the kernel's static arrays plus two counters per tile must fit the 64 KiB a workgroup may use; frames
-  // with more tiles than that (beyond ~5 900: 7680x4320 and up) are rasterised from the sorted list instead
+  // LDS budget: the kernel's static arrays plus a counter per tile must fit the 64 KiB a workgroup may use; frames
+  // with more tiles than that (7680x4320 and up) are rasterised from the sorted list instead
   static std::atomic<size_t> static_lds[3];  // per variant, asked once (a constant of the compiled kernel); 0 = not asked yet
   std::atomic<size_t> &slot = static_lds[bin_threads == 512 ? 2 : (bin_threads == 128 ? 1 : 0)];
   size_t lds = slot.load(std::memory_order_relaxed);
@@ -201,9 +267,12 @@ bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint
     lds = attr.sharedSizeBytes + 1;
     slot.store(lds, std::memory_order_relaxed);
   }
-  if ((lds - 1) + 2 * sizeof(uint32_t) * bin_tiles > 65536u || (uint32_t)(tiles_x * tiles_y) > MAX_TILES) return false;
-  hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bt), 2 * sizeof(uint32_t) * bin_tiles, st, recs, sorted, counts, cap, tiles_x,
-                     tiles_y, tile_hdr, entries, entry_cap, hits, overflow);
+  if ((lds - 1) + sizeof(uint32_t) * bin_tiles > 65536u || (uint32_t)(tiles_x * tiles_y) > MAX_TILES) return false;
+  // split lists need two more counters per tile (frames beyond ~4 000 tiles -- 5K and up -- keep whole-tile lists)
+  const bool split = want_split && (lds - 1) + 3 * sizeof(uint32_t) * bin_tiles <= 65536u;
+  *used_split = split;
+  hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bt), (split ? 3 : 1) * sizeof(uint32_t) * bin_tiles + 8, st, recs, sorted, counts, cap, tiles_x,
+                     tiles_y, tile_hdr, entries, entry_cap, hits, overflow, split ? 1u : 0u);
   return true;
 }
 

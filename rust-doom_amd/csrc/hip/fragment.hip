@@ -888,7 +888,11 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
     const TriRec *prec = recs + (size_t)pose * cap;
     const bool binned = overflow[pose] == 0u;
     const uint32_t T = (uint32_t)(tiles_x * tiles_y), tile = (uint32_t)((iy >> 6) * tiles_x + (ix >> 6));
-    const uint2 hdr = binned ? tile_hdr[(size_t)pose * T + tile] : make_uint2(0u, counts[pose]);
+    uint2 hdr = binned ? tile_hdr[(size_t)pose * T + tile] : make_uint2(0u, counts[pose]);
+    if (binned && (hdr.y & TILE_SPLIT)) {  // a tile with a list per quadrant (bin.hip): the list of the pixel's quadrant
+      const uint32_t *sh = entries + (size_t)pose * entry_cap + hdr.x + 2u * (uint32_t)(((iy >> 5) & 1) * 2 + ((ix >> 5) & 1));
+      hdr = make_uint2(sh[0], sh[1]);
+    }
     unsigned long long best = ~0ull;
     uint32_t best_rec = NONE;
     for (uint32_t base = 0; base < hdr.y; base += 64u) {

@@ -14,6 +14,9 @@
 namespace rdoom_dev {
 
 constexpr uint32_t MAX_TILES = 8192;     // tiles per frame the binning kernel keeps counters for
+// A tile whose list is longer than one batch of the rasteriser (one entry per lane) gets a list per 32 x 32 quadrant (bin.hip):
+// tile header word y carries TILE_SPLIT, word x points at (first entry, count) x 4 in the pose's entry array
+constexpr uint32_t LONG_LIST = 64, TILE_SPLIT = 0x80000000u;
 
 // Kernel 1: vertex stage, triangle setup, near-to-far record order (setup.hip)
 rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
@@ -25,14 +28,16 @@ size_t setup_histogram_bytes(uint32_t max_poses);  // scratch of the counting so
 // nothing was launched and the caller must flag every pose as "bins incomplete"
 bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
                 uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
-                uint2 *hits, uint32_t *overflow);
+                uint2 *hits, uint32_t *overflow,
+                bool want_split, bool *used_split);  // lists of more than LONG_LIST entries per quadrant, if the counters fit (bin.hip)
 // Kernel 2: tiled rasteriser -> visibility words (raster.hip)
 rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
                            const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out,
                            uint32_t *qtab,  // qtab (optional): per (pose, tile, quadrant) the record all its pixels show, or NONE
-                           bool skip_described_vis);  // no visibility words for quadrants the table describes (FragmentPlan)
+                           bool skip_described_vis,  // no visibility words for quadrants the table describes (FragmentPlan)
+                           bool split_lists);  // the binning kernel stored long lists per quadrant (launch_bin's answer for this render)
 // How the fragment kernel will walk a frame of this size, decided ONCE per render from the debug hooks (rasteriser and
 // fragment kernel must agree on who reads the quadrant table): quads per lane, log2(units per block row), blocks per
 // workgroup wave, the test hook leak_mod, and qtab_mode (0: table unused; 1 / 2: a wave block lies in one / two quadrants).

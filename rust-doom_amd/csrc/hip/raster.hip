@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "kernels.hpp"
 
@@ -277,7 +278,9 @@ constexpr uint32_t RASTER_WAVES = RDOOM_RASTER_WAVES;  // tiles (= waves) per wo
 // SKIPVIS: a quadrant the table describes ("all 1024 pixels show record r") gets NO visibility words: the fragment kernel
 // takes the record from the table wherever an entry exists and reads visibility words only where it says NONE
 // (launch_fragment's plan decides; 60 % of the quadrant passes of the 1080p sweep then store four bytes instead of 2 KB)
-template <bool STATS, bool VIS16, bool PRIM, bool SKIPVIS>
+// SPLIT: the binning kernel may have stored long lists per quadrant (bin.hip); without it the instantiation is the kernel as
+// it was before such lists existed (the caller chooses per render: renderer.hip)
+template <bool STATS, bool VIS16, bool PRIM, bool SKIPVIS, bool SPLIT>
 __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                              const uint4 *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts, uint32_t cap,
@@ -312,10 +315,15 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   const uint32_t over = overflow[pose], all_visible = counts[pose];
   const uint2 hdr_binned = tile_hdr[(size_t)pose * T + tile];
   const bool binned = over == 0u;  // the pose's per-tile lists are complete
+  // A tile with a long list (more than 64 entries: far geometry, small triangles that touch one quadrant each) comes with a list
+  // PER QUADRANT (bin.hip, "split lists"): each quadrant's pass starts with the gather of ITS list -- most of those fit one
+  // batch again (one gather, the shortcuts apply), and a quadrant's pass no longer gathers the records of the other three.
+  // pent / count / single then describe the current quadrant's list.
+  const bool split = SPLIT && binned && (hdr_binned.y & TILE_SPLIT) != 0u;
   const uint2 hdr = binned ? hdr_binned : make_uint2(0u, all_visible);
-  const uint32_t *pent = entries + (size_t)pose * entry_cap + hdr.x;
-  const uint32_t count = hdr.y;
-  const bool single = count <= 64u;  // the usual case: one gather serves all four quadrants
+  const uint32_t *pent = entries + (size_t)pose * entry_cap + hdr.x;  // (a split tile: set per quadrant)
+  uint32_t count = split ? 0u : hdr.y;
+  bool single = count <= 64u;  // the usual case: one gather serves all four quadrants
   uint32_t *myq = wq[wave];
   // what lane s keeps of the s-th entry of the current batch: record index, quadrant bits (touches: 0..3, covers:
   // 4..7), the depth plane, the nearest depth over each quadrant
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   uint32_t n = 0, myrq = 0, zpa = 0, zpb = 0, zpc = 0, dnq0 = NONE, dnq1 = NONE, dnq2 = NONE, dnq3 = NONE;
   // Gathers one batch of 64 list entries into the lanes (see the header: candidates, ranking, records, the per-quadrant
   // nearest depths and cover flags).  The usual tile has one batch, gathered once for its four quadrants.
-  auto gather = [&](uint32_t base) {
+  auto gather = [&](uint32_t base, const int qonly) {
     // ---- candidates: one per lane ----------------------------------------------------------------
     const uint32_t i = base + (uint32_t)lane;
     uint32_t cand = 0, qb = 0;
@@ -381,6 +389,10 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
         uint32_t dn[4], covx = 0u;
 #pragma unroll
         for (int qi = 0; qi < 4; qi++) {
+          if (qi != qonly && qonly >= 0) {  // (uniform) a split tile's gather serves one quadrant: the others' values are not used
+            dn[qi] = NONE;
+            continue;
+          }
           const int rx0 = tx0 + (qi & 1) * 32, ry0 = ty0 + (qi >> 1) * 32;
           const float xl = (float)rx0 + 0.5f, xh = (float)rx0 + 31.5f, yl = (float)ry0 + 0.5f, yh = (float)ry0 + 31.5f;
           const float zn = fmaf(za, pos(za) ? xl : xh, fmaf(zb, pos(zb) ? yl : yh, zc));
@@ -422,11 +434,11 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   asm volatile("" ::"s"(count));
 #endif
   RT_MARK(0);  // header, overflow flag, count
-  if (single && count != 0u) gather(0u);
+  if (single && count != 0u) gather(0u, -1);
   RT_MARK(1);  // list gather: entries, ranking, records, per-quadrant nearest depths and cover flags
 #ifdef RDOOM_TIMING_EXPERIMENTS  // the list gather and record set-up run twice: the difference in kernel time is their cost
   asm volatile("" ::: "memory");
-  if (single && count != 0u) gather(0u);
+  if (single && count != 0u) gather(0u, -1);
 #endif
 #ifndef RDOOM_NO_TILE_SHORTCUT
   // The same shortcut one level up: the tile's nearest entry (by its nearest depth over the quadrants it touches, not by its
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   // behind that entry's farthest depth over the whole tile.
   // (Whole tiles only: its stores carry no frame checks.  The quadrants of a tile that crosses the frame's edge take the
   // quadrant-level shortcut below.)
-  if (single && n != 0u && tx0 + TILE_W <= width && ty0 + TILE_H <= height) {
+  if (!split && single && n != 0u && tx0 + TILE_W <= width && ty0 + TILE_H <= height) {
     // my entry's nearest depth over the quadrants it touches (lanes without an entry hold NONE everywhere)
     const uint32_t tq = myrq >> 24;
     const uint32_t near_all = min(min((tq & 1u) ? dnq0 : NONE, (tq & 2u) ? dnq1 : NONE), min((tq & 4u) ? dnq2 : NONE, (tq & 8u) ? dnq3 : NONE));
@@ -490,6 +502,14 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
     if (qx0 >= width || qy0 >= height) continue;                    // entirely outside the frame (partial tiles)
     const int bx = qx0 + lx, by = qy0 + ly;                         // this lane's 4x4 block
     const float pxlo = (float)bx + 0.5f, pxhi = (float)bx + 3.5f, pylo = (float)by + 0.5f, pyhi = (float)by + 3.5f;
+    if (split) {  // this quadrant's own list: (first entry, count) from the tile's sub-header
+      const uint32_t *sh = entries + (size_t)pose * entry_cap + hdr.x + 2u * (uint32_t)q;
+      pent = entries + (size_t)pose * entry_cap + sh[0];
+      count = sh[1];
+      single = count <= 64u;
+      n = 0u;
+      if (single && count != 0u) gather(0u, q);
+    }
     if (single && n != 0u) {
       // Shortcut for the commonest quadrant of all: its nearest entry covers it entirely and every other entry of the
       // (complete, single-batch) list lies strictly behind that entry's FARTHEST depth over the quadrant -- the entry
@@ -656,7 +676,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
     bool had_cover = false;  // (uniform) some entry covers the whole quadrant
 #pragma unroll 1
     for (uint32_t base = 0; base < count; base += 64u) {
-      if (!single) gather(base);
+      if (!single) gather(base, split ? q : -1);
       if (n == 0u) continue;
       // ---- walk: the entries that touch this quadrant, near to far -------------------------------------------
       const uint32_t dnq = q == 0 ? dnq0 : (q == 1 ? dnq1 : (q == 2 ? dnq2 : dnq3));
@@ -807,7 +827,7 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
                            const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out, uint32_t *qtab,
-                           bool skip_described_vis) {
+                           bool skip_described_vis, bool split_lists) {
   const uint32_t n = n_poses;
   const uint32_t groups = (n + 7u) / 8u;  // pose groups of eight: one pose per XCD
   if (groups > 65535u || tiles_y > 65535 || (uint64_t)tiles_x * 8ull > 0x7FFFFFFFull)
@@ -819,13 +839,16 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
     HIP_TRY(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
   }
   const bool skip = skip_described_vis && qtab != nullptr;  // (without a table every visibility word is needed)
-  auto pick = [&](auto stats, auto skipvis) {
-    constexpr bool S = decltype(stats)::value, K = decltype(skipvis)::value;
-    return vis16 ? (prim_out ? raster_wave_kernel<S, true, true, K> : raster_wave_kernel<S, true, false, K>)
-                 : (prim_out ? raster_wave_kernel<S, false, true, K> : raster_wave_kernel<S, false, false, K>);
+  auto pick = [&](auto stats, auto skipvis, auto splt) {
+    constexpr bool S = decltype(stats)::value, K = decltype(skipvis)::value, P = decltype(splt)::value;
+    return vis16 ? (prim_out ? raster_wave_kernel<S, true, true, K, P> : raster_wave_kernel<S, true, false, K, P>)
+                 : (prim_out ? raster_wave_kernel<S, false, true, K, P> : raster_wave_kernel<S, false, false, K, P>);
   };
-  auto rk = dbg.raster_stats ? (skip ? pick(std::true_type{}, std::true_type{}) : pick(std::true_type{}, std::false_type{}))
-                             : (skip ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{}));
+  auto pick2 = [&](auto splt) {
+    return dbg.raster_stats ? (skip ? pick(std::true_type{}, std::true_type{}, splt) : pick(std::true_type{}, std::false_type{}, splt))
+                            : (skip ? pick(std::false_type{}, std::true_type{}, splt) : pick(std::false_type{}, std::false_type{}, splt));
+  };
+  auto rk = split_lists ? pick2(std::true_type{}) : pick2(std::false_type{});
   hipLaunchKernelGGL(rk, dim3((uint32_t)tiles_x * 8u, (uint32_t)tiles_y, groups), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, dbg.no_cover ? 1u : 0u,
                      qtab, d_stats);
@@ -858,6 +881,28 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
     unsigned long long h[16];
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     (void)hipFree(d_stats);
+    {  // census of the tile lists' lengths (a tile with more than 64 entries gets a list per quadrant: bin.hip)
+      const size_t nt = (size_t)n * (size_t)(tiles_x * tiles_y);
+      std::vector<uint2> hdrs(nt);
+      HIP_TRY(hipMemcpy(hdrs.data(), tile_hdr, sizeof(uint2) * nt, hipMemcpyDeviceToHost));
+      static const uint32_t edge[8] = {0u, 8u, 16u, 32u, 64u, 128u, 256u, 0xFFFFFFFFu};
+      unsigned long long tiles_in[8] = {}, entries_in[8] = {}, total = 0;
+      for (const uint2 &hd : hdrs) {
+        const uint32_t c = hd.y & ~TILE_SPLIT;
+        int k = 0;
+        while (c > edge[k]) k++;
+        tiles_in[k]++, entries_in[k] += c, total += c;
+      }
+      std::vector<uint32_t> ov(n);
+      HIP_TRY(hipMemcpy(ov.data(), overflow, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+      uint32_t n_over = 0;
+      for (uint32_t o : ov) n_over += o != 0u;
+      fprintf(stderr, "[rdoom stats] poses whose bins overflowed (rasterised from the sorted list; their headers below are stale): %u of %u\n", n_over, n);
+      fprintf(stderr, "[rdoom stats] tile lists: %.1f entries per tile;", (double)total / (double)nt);
+      static const char *names[8] = {"0", "1-8", "9-16", "17-32", "33-64", "65-128", "129-256", ">256"};
+      for (int k = 0; k < 8; k++) fprintf(stderr, "  %s: %.1f %% of the tiles, %.1f %% of the entries;", names[k], 100.0 * tiles_in[k] / (double)nt, total ? 100.0 * entries_in[k] / (double)total : 0.0);
+      fprintf(stderr, "\n");
+    }
     const double waves = (double)groups * 8.0 * (double)(tiles_x * tiles_y) * 4.0;  // (pose, quadrant) passes
     fprintf(stderr,
             "[rdoom stats] per quadrant pass: queue %.1f  past quadrant early-z %.1f  quadrant-cover %.2f  need-any %.1f (lanes %.1f)  fast %.1f (lanes %.1f)"

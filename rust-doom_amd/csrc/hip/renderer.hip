@@ -362,7 +362,11 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_visible, sizeof(uint32_t) * (size_t)b->cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_sorted, sizeof(uint4) * (size_t)b->cap * max_poses);
   b->n_tiles = ((width + TILE_W - 1) / TILE_W) * ((height + TILE_H - 1) / TILE_H);
-  b->entry_cap = std::max<uint32_t>(65536u, 32u * b->n_tiles);  // tile-list entries per pose; beyond it the pose is scanned
+  // tile-list entries per pose; beyond it the pose is rasterised from its sorted list (slow: every tile scans every visible
+  // triangle).  A long tile's list is stored per quadrant (bin.hip), an entry once per quadrant it touches, so the array is
+  // sized generously -- never beyond what the level could ever need: every triangle in every quadrant of every tile
+  b->entry_cap = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(131072u, 64u * b->n_tiles), (uint64_t)b->cap * b->n_tiles * 4u + 8u * (uint64_t)b->n_tiles);
+  b->entry_cap = (b->entry_cap + 3u) & ~3u;
   if (dbg.entry_cap > 0) b->entry_cap = (uint32_t)dbg.entry_cap;  // tests: force that fallback
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_tile_hdr, sizeof(uint2) * (size_t)b->n_tiles * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_entries, sizeof(uint32_t) * (size_t)b->entry_cap * max_poses);
@@ -466,9 +470,10 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
                                        b->d_ghist, b->cap, b->d_fix_count + 2))
       return rs;
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+  bool split_lists = false;  // long tile lists stored per quadrant this render (binning kernel and rasteriser must agree)
   if (!(lv->ntri && !rdoom::debug_options().no_bins &&
         launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
-                   b->entry_cap, b->d_hits, b->d_overflow))) {
+                   b->entry_cap, b->d_hits, b->d_overflow, !rdoom::debug_options().no_split, &split_lists))) {
     HIP_TRY(hipMemsetAsync(b->d_overflow, 0xFF, sizeof(uint32_t) * n, st));
     if (!lv->ntri) HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
   }
@@ -478,7 +483,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   const FragmentPlan plan = plan_fragment(W, H, b->d_qtab != nullptr);
   if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, W, H, tiles_x, tiles_y,
                                       b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out, b->d_qtab,
-                                      plan.skip_described_vis))
+                                      plan.skip_described_vis, split_lists))
     return rs;
   if (marks) HIP_TRY(hipEventRecord(ev[2], st));
   if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, b->d_poses, W, H, tiles_x,

@@ -33,7 +33,7 @@ rdoom_status rdoom_debug_set(const char *name, int32_t value) {
                {"leak_mod", &o.leak_mod},   {"frag_nq", &o.frag_nq},       {"frag_bw", &o.frag_bw},
                {"frag_chunk", &o.frag_chunk}, {"bin_threads", &o.bin_threads}, {"no_cover", &o.no_cover},
                {"raster_stats", &o.raster_stats}, {"no_qtab", &o.no_qtab},
-               {"keep_vis", &o.keep_vis},   {"qpath", &o.qpath}};
+               {"keep_vis", &o.keep_vis},   {"qpath", &o.qpath},           {"no_split", &o.no_split}};
   for (const auto &t : table)
     if (std::strcmp(t.name, name) == 0) {
       *t.field = value;

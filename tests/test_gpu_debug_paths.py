@@ -15,6 +15,9 @@ process sets its own, they are process-wide).  Every hook selects an equivalent 
   qpath=1        the whole-quadrant fragment kernel runs first (fragment_quadrant_kernel shades the described quadrants whose record
                  qualifies -- queueing uncertified-mod runs and transparent texels for fixup_kernel -- and fragment_kernel skips
                  the blocks that lie in them; off by default: measured slower than fragment_kernel alone).
+  no_split=1     no list per quadrant for the tiles whose list holds more than 64 entries (bin.hip "split lists": the rasteriser
+                 takes such a tile as four parts, each quadrant with its own list; without them it re-gathers the whole list
+                 for every quadrant).
 Each child renders another set of poses into its batch before the checked render: whatever the checked render does not write
 holds another frame's values.  The image is checked with and without primitive ids."""
 import os
@@ -118,6 +121,18 @@ def test_quadrant_path_at_larger_frames(args):
     queued), partial quadrants at the frame's bottom (1080 = 33.75 x 32)"""
     bad, _ = run_child({'qpath': 1}, args)
     assert bad == 0, args
+
+
+@pytest.mark.parametrize('hooks', [{}, {'no_split': 1}, {'no_split': 1, 'no_cover': 1}, {'no_cover': 1}, {'keep_vis': 1, 'no_split': 1}, {'vis32': 1},
+                                   {'leak_mod': 7}, {'leak_mod': 7, 'no_split': 1}, {'bin_threads': 128}, {'bin_threads': 512, 'no_qtab': 1}])
+def test_long_tile_lists_split_by_quadrant_or_not(hooks):
+    """frames whose far tiles hold long lists (320 x 200: a quarter of the tiles hold more than 64 entries, some several
+    hundred -- quadrant lists that fit one batch and take the shortcuts, quadrant lists of several batches, quadrants outside
+    the frame, entries that touch several quadrants and are in each of their lists) with the per-quadrant lists (default)
+    and without (no_split); leak_mod sends pixels of such tiles through fixup_kernel, which reads the pixel's quadrant's list"""
+    for args in (('0', '320', '200', '6'), ('2', '200', '136', '4'), ('5', '712', '296', '3')):
+        bad, _ = run_child(hooks, args)
+        assert bad == 0, (hooks, args)
 
 
 def test_child_case_plain():
