@@ -19,7 +19,7 @@ struct DebugOptions {
   int frag_nq = 2;       // quads per lane in the fragment kernel (1 = the variant for widths that are not a multiple of 8)
   int frag_bw = 3;       // log2(units per row of the fragment kernel's wave block)
   int frag_chunk = 0;    // wave blocks per wave in the fragment kernel (0 = default)
-  int bin_threads = 256; // workgroup size of the binning kernel
+  int bin_threads = 0;   // workgroup size of the binning kernel (0 = by frame size: bin.hip)
   int no_cover = 0;      // no depth-only body for quadrant-covering triangles
   int no_qtab = 0;       // the fragment kernel ignores the rasteriser's quadrant table (every wave reads its visibility words)
   int qpath = 0;         // the whole-quadrant fragment kernel runs first (off by default: measured slower)

@@ -16,7 +16,10 @@ namespace rdoom_dev {
 constexpr uint32_t MAX_TILES = 8192;     // tiles per frame the binning kernel keeps counters for
 // A tile whose list is longer than one batch of the rasteriser (one entry per lane) gets a list per 32 x 32 quadrant (bin.hip):
 // tile header word y carries TILE_SPLIT, word x points at (first entry, count) x 4 in the pose's entry array
-constexpr uint32_t LONG_LIST = 64, TILE_SPLIT = 0x80000000u;
+#ifndef RDOOM_LONG_LIST
+#define RDOOM_LONG_LIST 64
+#endif
+constexpr uint32_t LONG_LIST = RDOOM_LONG_LIST, TILE_SPLIT = 0x80000000u;
 
 // Kernel 1: vertex stage, triangle setup, near-to-far record order (setup.hip)
 rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,

@@ -29,5 +29,6 @@ def test_hot_kernels_use_no_scratch():
     assert all(res[k]['vgpr_count'] <= 80 for k in res if k.startswith('fragment_kernel<'))
     # LDS per workgroup: COLORMAP (8 KiB) + the per-wave quad lists in the fragment kernel; the parked records in the rasteriser
     assert res['fragment_kernel<2, 0, true>']['group_segment_fixed_size'] <= 12 * 1024
-    assert res['raster_wave_kernel<false, true, false, true>']['group_segment_fixed_size'] <= 6 * 1024  # (no stats, 16-bit words, no ids, SKIPVIS;
+    for split in ('false', 'true'):  # (the instantiation without / with the per-quadrant lists of long tiles)
+        assert res['raster_wave_kernel<false, true, false, true, %s>' % split]['group_segment_fixed_size'] <= 6 * 1024  # (no stats, 16-bit words, no ids, SKIPVIS;
     # 4 KiB of parked records + 1 KiB of edge hashes / cover-but-for-one-edge bits + the list scratch: 16 one-wave workgroups per CU use 84 of 160 KiB)
