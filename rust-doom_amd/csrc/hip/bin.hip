@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *tmp) {
 }
 
 #ifndef RDOOM_BIN_OCC
-#define RDOOM_BIN_OCC 1  // waves per SIMD the register allocation must allow
+#define RDOOM_BIN_OCC 4  // waves per SIMD the register allocation must allow (128 VGPRs: all 1024 workgroups of a 1024-pose batch resident at once)
 #endif
 template <int BIN_THREADS, int BIN_LOG2>  // threads per workgroup = triangles staged per round (one per thread)
 __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const TriRec *__restrict__ recs,
@@ -127,10 +127,23 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
           // (rect_may_touch is conservative and hierarchical), so no tile that passes the per-tile test is lost.
           const float fx0 = (float)(tx0 * 64) + 0.5f, fx1 = (float)(tx1 * 64) + 63.5f;
           const float fy0 = (float)(ty0 * 64) + 0.5f, fy1 = (float)(ty1 * 64) + 63.5f;
-          while (ty0 <= ty1 && !rect_may_touch(c0, c1, c2, fx0, fx1, (float)(ty0 * 64) + 0.5f, (float)(ty0 * 64) + 63.5f)) ty0++;
-          while (ty1 >= ty0 && !rect_may_touch(c0, c1, c2, fx0, fx1, (float)(ty1 * 64) + 0.5f, (float)(ty1 * 64) + 63.5f)) ty1--;
-          while (tx0 <= tx1 && !rect_may_touch(c0, c1, c2, (float)(tx0 * 64) + 0.5f, (float)(tx0 * 64) + 63.5f, fy0, fy1)) tx0++;
-          while (tx1 >= tx0 && !rect_may_touch(c0, c1, c2, (float)(tx1 * 64) + 0.5f, (float)(tx1 * 64) + 63.5f, fy0, fy1)) tx1--;
+          // (one loop over the four sides -- first rows from the top, last rows, first columns, last columns -- so that
+          // rect_may_touch is inlined once: this rare path must not cost the kernel registers)
+          int side = 0;
+#pragma unroll 1
+          while (side < 4 && tx0 <= tx1 && ty0 <= ty1) {
+            const bool rows = side < 2;
+            const int t = side == 0 ? ty0 : (side == 1 ? ty1 : (side == 2 ? tx0 : tx1));
+            const float lo = (float)(t * 64) + 0.5f, hi = (float)(t * 64) + 63.5f;
+            if (rect_may_touch(c0, c1, c2, rows ? fx0 : lo, rows ? fx1 : hi, rows ? lo : fy0, rows ? hi : fy1)) {
+              side++;
+            } else {
+              ty0 += side == 0;
+              ty1 -= side == 1;
+              tx0 += side == 2;
+              tx1 -= side == 3;
+            }
+          }
         }
         nt = (tx1 >= tx0 && ty1 >= ty0) ? (uint32_t)((tx1 - tx0 + 1) * (ty1 - ty0 + 1)) : 0u;
         trange[tid] = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)(tx1 - tx0 + 1) << 16);  // tiles per side <= 128
