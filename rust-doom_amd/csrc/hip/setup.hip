@@ -34,7 +34,8 @@ namespace {
 // =================================================================================================
 constexpr uint32_t SORT_BUCKETS = 2048;
 constexpr uint32_t CULL_CHUNK = 1024;  // triangle slots culled per outer iteration (four per thread), survivors set up densely
-constexpr uint32_t CLUSTER_LIST = 4096;  // clusters whose survivors fit the LDS list (larger levels: no coarse cull)
+constexpr uint32_t CLUSTER_LIST = 1024;  // clusters of a workgroup's share whose survivors fit the LDS list (16 workgroups per pose: levels of up to
+                                         // half a million triangles; larger ones: no coarse cull)
 
 // Coarse cull of a cluster (exact implications, no new rule): true only if EVERY triangle whose vertices lie in the box
 // fails S1 or S6.  A clip coordinate is one fmaf chain over (x, y, z), monotone in each of them, so its extremes over the
@@ -228,17 +229,27 @@ __device__ __forceinline__ uint32_t depth_bucket(float wmin) {
   return min(b, SORT_BUCKETS - 1u);
 }
 
-__global__ __launch_bounds__(256) void cull_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
+#ifndef RDOOM_CULL_OCC
+#define RDOOM_CULL_OCC 1
+#endif
+#ifndef RDOOM_SETUP_OCC
+#define RDOOM_SETUP_OCC 1
+#endif
+__global__ __launch_bounds__(256, RDOOM_CULL_OCC) void cull_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
                                                    const ObjectConst *__restrict__ objects, uint32_t n_objects,
                                                    int width, int height, uint32_t kinds_mask,
                                                    uint32_t *__restrict__ visible, uint32_t *__restrict__ counts,
                                                    uint32_t *__restrict__ ghist, uint32_t cap, uint32_t groups) {
   __shared__ uint32_t hist[SORT_BUCKETS];   // this workgroup's share of the pose's depth-bucket histogram
-  __shared__ uint32_t cand[CULL_CHUNK];     // this chunk's visible triangles
   __shared__ uint16_t clist[CLUSTER_LIST];  // my clusters that survived the coarse cull, ascending
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t chunk_first;          // where this chunk's records go in the pose's staging array
   __shared__ uint4 wstage[4][384];  // per wave: 2 x 32 level triangles (6 x 16 B each)
+  // this chunk's visible triangles: written after the barrier that ends the chunk's cull steps and read before the one that
+  // ends the chunk, i.e. while no wave uses its stage -- the list shares wave 0's (4 of its 6 KiB); 34 KiB of LDS: four
+  // workgroups per CU
+  uint32_t *cand = reinterpret_cast<uint32_t *>(wstage[0]);
+  static_assert(sizeof(uint32_t) * CULL_CHUNK <= sizeof(uint4) * 384, "cull_kernel: cand does not fit a wave's stage");
   const uint32_t pose = blockIdx.y, group = blockIdx.x;
   const PoseConst &pc = poses[pose];
   const ObjectConst *objs = objects ? objects + (size_t)pose * n_objects : nullptr;
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ g
 // near-to-far position (scanned histogram + one atomic): record index == position in the sorted list from here on (bin /
 // raster / fragment gather records by that index).  The order inside a bucket is whatever the atomics hand out (nothing
 // depends on it).  A few workgroups per pose, each striding over the pose's list of visible triangles.
-__global__ __launch_bounds__(256) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
+__global__ __launch_bounds__(256, RDOOM_SETUP_OCC) void setup_kernel(DeviceLevelView lv, const PoseConst *__restrict__ poses,
                                                     const ObjectConst *__restrict__ objects, uint32_t n_objects,
                                                     int width, int height, uint32_t kinds_mask,
                                                     const uint32_t *__restrict__ visible, TriRec *__restrict__ recs,
