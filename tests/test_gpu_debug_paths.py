@@ -135,6 +135,14 @@ def test_long_tile_lists_split_by_quadrant_or_not(hooks):
         assert bad == 0, (hooks, args)
 
 
+@pytest.mark.parametrize('size', [(5120, 2880), (6144, 3456)])
+def test_frames_around_the_split_lists_tile_limit(size):
+    """the binning kernel keeps three LDS counters per tile for the per-quadrant lists: a 5K frame (3 600 tiles) still has
+    them, a 6K frame (5 184 tiles) falls back to whole-tile lists and the rasteriser's instantiation without them"""
+    bad, _ = run_child({}, ('0', str(size[0]), str(size[1]), '1'))
+    assert bad == 0, size
+
+
 def test_child_case_plain():
     bad, fixups = run_child({})
     assert bad == 0 and fixups < 1000
