@@ -17,9 +17,15 @@ Workloads (BASELINE.json configs):
 Multi-GPU: one process per GPU, no data-path collective (poses are independent; torch.distributed is used ONLY for the
 timing barrier and the max-over-ranks reduction).  `--gpus N` launched WITHOUT a torch.distributed environment spawns
 the N ranks itself (python -m torch.distributed.run, 127.0.0.1); under torchrun it is one rank of WORLD_SIZE.
-The rank's poses are rendered as two half-batches on two HIP streams (`--streams`, default 2): one half's rasteriser
-overlaps the other's fragment kernel; `kernels_ms` and `roofline` then come from a single-stream pass of the same steps
-after the timed region (with `--streams 1` from the timed region itself).
+The rank's renders are spread over a small pool of HIP streams (`--streams`, default: auto): with ONE level its poses are cut
+into S sub-batches, one per stream (auto: 2 -- one half's rasteriser overlaps the other's fragment kernel); with several levels
+(config 4) the levels ALTERNATE over the pool, each as one batch (auto: 3) -- one level's latency-bound set-up and binning
+kernels run under another's rasteriser and fragment kernel, which is what keeps a small share of the batch (strong scaling:
+128 poses per level and GPU at 8 GPUs) near the full batch's rate.  `kernels_ms` and `roofline` then come from a single-stream
+pass of the same steps after the timed region (with `--streams 1` from the timed region itself).
+`--share G` adds the strong-scaling proxy a one-GPU box can give: the same workload with poses / G per level (the share of one
+of G GPUs), timed the same way; `scaling_proxy.predicted_speedup_at_G` = full step time / share step time (a PREDICTION: the
+other G - 1 GPUs are assumed to do as well on their shares; nothing is exchanged between them).
 `--scaling weak` (default): every rank renders its own `--poses` poses; `--scaling strong`: ONE batch of `--poses`
 poses is cut into contiguous ranges.  When fewer GPUs are present than ranks (a one-GPU box), ranks wrap onto the GPUs
 present over gloo -- that exercises the code path, it is not a scaling measurement, and the line says so
@@ -65,11 +71,22 @@ def parse_args(argv=None):
     ap.add_argument('--big', action='store_true', help='the 10x-E1M1 synthetic level (stand-in for DOOM2 MAP29)')
     ap.add_argument('--iwad', default=None)
     ap.add_argument('--metadata', default=None)
-    ap.add_argument('--streams', type=int, default=2,
-                    help='the rank\'s poses as S sub-batches on S HIP streams (default 2: one half\'s rasteriser overlaps the '
-                         'other\'s fragment kernel).  With S > 1 the kernels overlap, so their own durations -- kernels_ms, the '
+    ap.add_argument('--streams', type=int, default=0,
+                    help='HIP streams the rank\'s renders are spread over (0 = auto: 2 with one level -- its poses as two sub-batches, '
+                         'one half\'s rasteriser overlaps the other\'s fragment kernel; 3 with several levels, which alternate over '
+                         'the pool as one batch each).  With S > 1 the kernels overlap, so their own durations -- kernels_ms, the '
                          'roofline -- are measured in a single-stream pass of the same K steps AFTER the timed region; S = 1 '
                          'measures them in the timed region itself')
+    ap.add_argument('--share', type=int, default=0, metavar='G',
+                    help='strong-scaling proxy on ONE GPU: after the headline the same workload is timed with poses / G per level '
+                         '(what one of G GPUs would render under --scaling strong); prints scaling_proxy')
+    ap.add_argument('--long', type=float, default=0.0, metavar='SECONDS',
+                    help='raise the number of timed steps until the timed region lasts at least this long (e.g. --long 2: an '
+                         'external sampler then sees the GPU busy); the line\'s `steps` is the number really timed.  Default: exactly --steps')
+    ap.add_argument('--launcher', choices=('processes', 'threads'), default='processes',
+                    help='--gpus N > 1: one PROCESS per GPU (torch.distributed.run; RCCL for the timing barrier only), or one process '
+                         'with one host THREAD per GPU driving the C ABI directly (what INTEGRATION.md tells a Rust host to do; '
+                         'threads wrap onto the GPUs present)')
     ap.add_argument('--cpu-sample', type=int, default=512, help='poses rendered by the CPU oracle (0 = skip)')
     ap.add_argument('--debug', action='append', default=[], metavar='NAME=VALUE',
                     help='experiment: rdoom_debug_set hook (an equivalent path: same image), e.g. frag_bw=2; repeatable')
@@ -118,8 +135,35 @@ def measurement_key(args, levels):
     return '%s|streams=%d' % (workload_key(args, levels), args.streams)
 
 
+def resolve_streams(requested, n_levels):
+    """--streams 0 = auto: two sub-batches of the one level's poses, or three streams that several levels alternate over"""
+    return requested if requested > 0 else (2 if n_levels == 1 else 3)
+
+
+def parts_per_level(n_levels, streams):
+    """sub-batches a level's poses are cut into: S for one level; with several levels each is ONE batch (they alternate over the
+    stream pool) unless there are fewer levels than streams"""
+    if n_levels == 1:
+        return streams
+    return 1 if n_levels >= streams else -(-streams // n_levels)
+
+
+def merge_path_stats(batches):
+    """rdoom_batch_path_stats of the batches' last renders, summed: which paths the workload took"""
+    tot = {}
+    for b in batches:
+        for k, v in b.path_stats().items():
+            tot[k] = tot.get(k, 0) + v
+    if not tot or not tot.get('tiles'):
+        return None
+    return {'bins_overflowed_poses': tot['bins_overflowed_poses'], 'poses': tot['poses'],
+            'split_tiles_pct': round(100.0 * tot['split_tiles'] / tot['tiles'], 2),
+            'entries_per_tile': round(tot['tile_entries'] / tot['tiles'], 1),
+            'described_quadrants_pct': round(100.0 * tot['described_quadrants'] / max(1, tot['quadrants']), 1)}
+
+
 OTHER_WORKLOADS = (   # BASELINE configs 2 / 4 / 5 (and the 4K frame) in short: what the driver's one command would otherwise never see
-    dict(name='config 4 on one GPU: E1M1..E1M9, one batch per level', levels=list(range(9)), big=False, width=1920, height=1080, poses=512, tv=False),
+    dict(name='config 4 on one GPU: E1M1..E1M9, one batch per level', levels=list(range(9)), big=False, width=1920, height=1080, poses=1024, tv=False, share=8),
     dict(name='config 5 class: 10x-E1M1 (MAP29 stand-in), pose i at time i/35 s with its own light table', levels=[0], big=True, width=3840, height=2160, poses=256, tv=True),
     # (small frames: the set-up kernels -- a third of that step, latency-bound -- overlap better over three sub-batches than two)
     dict(name='config 2 frame size: E1M1', levels=[0], big=False, width=320, height=200, poses=8192, tv=False, streams=3),
@@ -127,12 +171,15 @@ OTHER_WORKLOADS = (   # BASELINE configs 2 / 4 / 5 (and the 4K frame) in short: 
 )
 
 
-def quick_line(rd, torch, sharding, wad, spec, streams, steps=8, warmup=2):
-    """One short measurement of another workload, timed like the headline: the poses of every level as `streams` sub-batches on
-    `streams` HIP streams (value), then as ONE batch on one stream for the per-kernel times."""
+def quick_line(rd, torch, sharding, wad, spec, streams, steps=8, warmup=2, kernels=True):
+    """One short measurement of another workload, timed like the headline: the renders of a step spread over `streams` HIP
+    streams (value), then every level as ONE batch on one stream for the per-kernel times (kernels=False: skipped)."""
     w, h, n = spec['width'], spec['height'], spec['poses']
+    n_levels = len(spec['levels'])
+    parts = parts_per_level(n_levels, streams)
+    pool = [torch.cuda.Stream() for _ in range(streams)] if streams > 1 else [None]
     work, full, closers = [], [], []
-    for index in spec['levels']:
+    for li, index in enumerate(spec['levels']):
         built = wad.build_level(index, gpu_tessellation=True)
         level = rd.DeviceLevel(built)
         poses = sharding.pose_sweep(rd, built, n, w, h)
@@ -141,20 +188,24 @@ def quick_line(rd, torch, sharding, wad, spec, streams, steps=8, warmup=2):
             lights = np.stack([built.lights_at(float(t)) for t in poses['time']])
         else:
             lights = built.lights_at(0.0)
-        for part in range(streams):
-            lo, hi = sharding.shard_range(n, part, streams)
+        for part in range(parts):
+            lo, hi = sharding.shard_range(n, part, parts)
             if hi > lo:
                 b = rd.Batch(level, w, h, hi - lo)
-                work.append((b, poses[lo:hi], lights[lo:hi] if spec['tv'] else lights, torch.cuda.Stream()))
+                work.append((b, poses[lo:hi], lights[lo:hi] if spec['tv'] else lights, pool[(li * parts + part) % len(pool)]))
                 closers.append(b)
-        b = rd.Batch(level, w, h, n)
-        full.append((b, poses, lights, None))
-        closers += [b, level, built]
+        if parts == 1:
+            full.append((work[-1][0], poses, lights, None))   # the same batch, on the default stream
+        else:
+            b = rd.Batch(level, w, h, n)
+            full.append((b, poses, lights, None))
+            closers.append(b)
+        closers += [level, built]
 
-    def run(items, k):
+    def run(items, k, profiled):
         for _ in range(k):
             for b, p, l, st in items:
-                b.render_profiled(p, l, stream=st.cuda_stream if st is not None else None)
+                (b.render_profiled if profiled else b.render)(p, l, stream=st.cuda_stream if st is not None else None)
 
     def collect(items):
         acc = {'setup_ms': 0.0, 'raster_ms': 0.0, 'fragment_ms': 0.0}
@@ -164,28 +215,55 @@ def quick_line(rd, torch, sharding, wad, spec, streams, steps=8, warmup=2):
                 acc[k] += t[k]
         return acc
 
-    run(work, warmup)
+    # (with several streams the per-kernel events would only add barriers between the kernels of a stream: plain renders)
+    run(work, warmup, streams == 1)
     collect(work)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(work, steps)
+    run(work, steps, streams == 1)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    collect(work)
-    run(full, warmup)
-    collect(full)
-    torch.cuda.synchronize()
-    run(full, steps)
-    torch.cuda.synchronize()
-    acc = collect(full)
-    px = n * w * h * len(spec['levels'])
-    frag = acc['fragment_ms'] / steps
+    acc = collect(work)
+    if streams > 1 and kernels:
+        run(full, warmup, True)
+        collect(full)
+        torch.cuda.synchronize()
+        run(full, steps, True)
+        torch.cuda.synchronize()
+        acc = collect(full)
+    px = n * w * h * n_levels
+    out = {'workload': '%s, %d poses%s at %dx%d' % (spec['name'], n, ' per level' if n_levels > 1 else '', w, h),
+           'value': round(px * steps / elapsed / 1e6, 1), 'unit': 'Mpixels/s', 'ms_per_step': round(elapsed / steps * 1e3, 3), 'steps': steps, 'streams': streams,
+           'stream_plan': ('%d sub-batches of the level\'s poses, one per stream' % parts) if n_levels == 1 else
+                          ('the %d levels alternate over the %d streams, %s' % (n_levels, streams, 'one batch each' if parts == 1 else '%d sub-batches each' % parts))}
+    if streams == 1 or kernels:
+        frag = acc['fragment_ms'] / steps
+        out['kernels_ms'] = {k[:-3]: round(acc[k] / steps, 3) for k in ('setup_ms', 'raster_ms', 'fragment_ms')}
+        out['roofline_frac'] = round(px * ALG_READ_BYTES_PER_PIXEL / (frag * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frag > 0 else None
+    out['paths'] = merge_path_stats([item[0] for item in (full if (streams > 1 and kernels) else work)])
     for c in closers:
         c.close()
-    return {'workload': '%s, %d poses%s at %dx%d' % (spec['name'], n, ' per level' if len(spec['levels']) > 1 else '', w, h),
-            'value': round(px * steps / elapsed / 1e6, 1), 'unit': 'Mpixels/s', 'ms_per_step': round(elapsed / steps * 1e3, 3), 'steps': steps, 'streams': streams,
-            'kernels_ms': {k[:-3]: round(acc[k] / steps, 3) for k in ('setup_ms', 'raster_ms', 'fragment_ms')},
-            'roofline_frac': round(px * ALG_READ_BYTES_PER_PIXEL / (frag * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frag > 0 else None}
+    return out
+
+
+def scaling_proxy(rd, torch, sharding, wad, spec, G, full_line, steps=8, warmup=2):
+    """The strong-scaling share a one-GPU box can measure: the workload of `spec` with poses / G per level -- what ONE of G GPUs renders
+    under --scaling strong (its contiguous range of every level's batch) -- timed like the full batch, on 1, 2 and 3 streams.
+    predicted_speedup_at_G = full step time / best share step time: the speed-up G GPUs would give IF each did as well on its
+    share as this one (nothing is exchanged between them: DESIGN section 6).  A prediction, not a scaling measurement."""
+    share = dict(spec, poses=max(1, spec['poses'] // G), name=spec['name'] + ' -- the 1/%d share' % G)
+    lines = {}
+    for s in (1, 2, 3):
+        lines[s] = quick_line(rd, torch, sharding, wad, share, s, steps=steps, warmup=warmup, kernels=(s == 1))
+    best = min(lines, key=lambda k: lines[k]['ms_per_step'])
+    return {'gpus': G, 'poses_per_level_full': spec['poses'], 'poses_per_level_share': share['poses'],
+            'full_ms': full_line['ms_per_step'], 'full_streams': full_line['streams'],
+            'share_ms_by_streams': {str(k): v['ms_per_step'] for k, v in lines.items()}, 'share_ms': lines[best]['ms_per_step'],
+            'share_streams': best, 'share_kernels_ms_one_stream': lines[1].get('kernels_ms'),
+            'predicted_speedup_at_%d' % G: round(full_line['ms_per_step'] / lines[best]['ms_per_step'], 2),
+            'ideal_share_ms': round(full_line['ms_per_step'] / G, 3),
+            'what': 'one GPU, the same box and library: full = %d poses per level, share = %d (the contiguous range one of %d GPUs renders under '
+                    '--scaling strong); a prediction from one GPU, not a scaling measurement' % (spec['poses'], share['poses'], G)}
 
 
 def usable_cores():
@@ -251,8 +329,123 @@ def dry_run(args, rank, world, rd, sharding, synthetic):
                           'pose_ranges': [list(r) for r in ranges]}), flush=True)
 
 
+def run_threads(args):
+    """--launcher threads: ONE process, one host thread per GPU, the C ABI only (no torch, no torch.distributed) -- the shape
+    INTEGRATION.md gives a Rust host: a `std::thread` per device, each with its own rdoom_wad handle (the reference's Archive is
+    !Sync), its own level copy, batches and streams; a barrier on both sides of the timed region, the slowest thread's time
+    counts.  With fewer GPUs than threads the threads wrap onto the GPUs present (exercises the path; the line says so).
+    --dry-run: everything but the device work."""
+    import ctypes
+    import threading
+    import rust_doom_amd as rd
+    sharding = importlib.import_module('rust-doom_amd.sharding')
+    synthetic = importlib.import_module('rust-doom_amd.synthetic')
+    world, levels = args.gpus, level_list(args)
+    iwad = args.iwad or (synthetic.ensure_big_wad() if args.big else synthetic.ensure_wad())
+    meta = args.metadata or synthetic.META_PATH
+    present = 0 if args.dry_run else rd.device_count()
+    if not args.dry_run and present < 1:
+        raise SystemExit('bench.py needs a GPU: there is no CPU fallback (--dry-run checks the launch and the partition only)')
+    hip = None if args.dry_run else ctypes.CDLL('libamdhip64.so')
+    for item in args.debug:
+        name, _, value = item.partition('=')
+        rd.debug_set(name, int(value or 1))
+    barrier = threading.Barrier(world)
+    elapsed, ranges, errors = [0.0] * world, [None] * world, []
+    parts = parts_per_level(len(levels), args.streams)
+
+    def worker(rank):
+        try:
+            lo, hi = sharding.shard_range(args.poses, rank, world) if args.scaling == 'strong' else (rank * args.poses, (rank + 1) * args.poses)
+            wad = rd.Wad(iwad, meta)                 # one handle per thread
+            if args.dry_run:
+                built = wad.build_level(levels[0])
+                poses = sharding.pose_sweep(rd, built, hi - lo, args.width, args.height, first=lo)
+                ranges[rank] = (lo, hi, hashlib.sha256(poses.tobytes()).hexdigest()[:16])
+                barrier.wait()
+                return
+            rd.set_device(rank % present)             # hipSetDevice is per host thread
+            pool = []
+            for _ in range(args.streams):
+                st = ctypes.c_void_p()
+                if hip.hipStreamCreate(ctypes.byref(st)) != 0:
+                    raise RuntimeError('hipStreamCreate failed')
+                pool.append(st)
+            work = []
+            for li, index in enumerate(levels):
+                built = wad.build_level(index, gpu_tessellation=True)
+                level = rd.DeviceLevel(built)         # one copy of the level per device (replicated: SURVEY 8(e))
+                lights0 = built.lights_at(0.0)
+                for part in range(parts):
+                    plo, phi = lo + sharding.shard_range(hi - lo, part, parts)[0], lo + sharding.shard_range(hi - lo, part, parts)[1]
+                    if phi <= plo:
+                        continue
+                    poses = sharding.pose_sweep(rd, built, phi - plo, args.width, args.height, first=plo)
+                    lights = lights0
+                    if args.time_varying:
+                        poses['time'] = (np.arange(plo, phi) / 35.0).astype(np.float32)
+                        lights = np.stack([built.lights_at(float(t)) for t in poses['time']])
+                    work.append((rd.Batch(level, args.width, args.height, phi - plo), poses, lights, pool[(li * parts + part) % len(pool)].value, level, built))
+            ranges[rank] = (lo, hi)
+
+            def steps(k):
+                for _ in range(k):
+                    for b, p, l, st, _lv, _bu in work:
+                        b.render(p, l, stream=st)
+                for b, *_ in work:
+                    b.finish()                        # waits for THIS batch's stream only; raises if the device flagged a problem
+
+            steps(args.warmup)
+            barrier.wait()
+            t0 = time.perf_counter()
+            steps(args.steps)
+            elapsed[rank] = time.perf_counter() - t0
+            barrier.wait()
+            for b, *_ in work:
+                b.close()
+            for st in pool:
+                hip.hipStreamDestroy(st)
+        except Exception as e:  # noqa: BLE001  (reported by the main thread)
+            errors.append((rank, repr(e)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise SystemExit('bench.py --launcher threads: %r' % errors)
+    if args.dry_run:
+        print(json.dumps({'dry_run': True, 'value': None, 'n_gpus': world, 'launcher': 'threads', 'scaling': args.scaling, 'levels': levels,
+                          'pose_ranges': [list(r) for r in ranges]}), flush=True)
+        return
+    t = max(elapsed)
+    frame_px = args.width * args.height
+    poses_global = (args.poses if args.scaling == 'strong' else args.poses * world) * len(levels)
+    out = {'metric': metric_label(args, levels), 'value': round(poses_global * frame_px * args.steps / t / 1e6, 1), 'unit': 'Mpixels/s', 'n_gpus': world,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(t / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling,
+           'vs_baseline': None, 'dtype': 'f32+u8', 'data': 'synthetic', 'frames_per_s': round(poses_global * args.steps / t, 1),
+           'config': {'workload': '%s, %d poses %s at %dx%d' % (metric_label(args, levels), args.poses, 'per GPU' if args.scaling == 'weak' else 'in total, cut into contiguous ranges',
+                                                                 args.width, args.height),
+                      'levels': levels, 'launcher': 'threads: one process, one host thread per GPU, C ABI only', 'streams': args.streams,
+                      'pose_ranges': [list(r) for r in ranges], 'parallelism': 'pose-sharded x%d, no collective' % world,
+                      'kernel_sources': kernel_source_digest()},
+           'per_thread_ms_per_step': [round(e / args.steps * 1e3, 3) for e in elapsed],
+           'roofline': None, 'cpu_baseline': None,
+           'note_launcher': 'roofline / cpu_baseline are N = 1 measurements of the default (process) launcher'}
+    if present < world:
+        out['gpus_present'] = present
+        out['note'] = '%d threads wrapped onto %d GPU(s): exercises the N > 1 path, not a scaling measurement' % (world, present)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
+    cli_streams = args.streams
+    args.streams = resolve_streams(args.streams, len(level_list(args)))
+    if args.launcher == 'threads':
+        return run_threads(args)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
 
@@ -297,18 +490,20 @@ def main():
     else:
         lo, hi = rank * args.poses, (rank + 1) * args.poses      # every GPU its own batch
     n_mine = hi - lo
-    work, work_full, tstreams = [], [], []
+    work, work_full = [], []
     t_build = 0.0
-    for index in levels:
+    # the stream pool (--streams S): one level -> its poses as S sub-batches, one per stream (one sub-batch's rasteriser overlaps
+    # another's fragment kernel); several levels -> they alternate over the pool, one batch each (parts_per_level)
+    tstreams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else []
+    parts = parts_per_level(len(levels), args.streams)
+    for li, index in enumerate(levels):
         t0 = time.perf_counter()
         built = wad.build_level(index, gpu_tessellation=True)   # SSECTOR -> polygon, SEG -> quad kernels
         t_build += time.perf_counter() - t0
         level = rd.DeviceLevel(built)                            # level arrays now resident in HBM
-        # --streams S (experiment, default 1): the rank's poses as S sub-batches on S HIP streams, so that one
-        # sub-batch's rasteriser overlaps another's fragment kernel
-        for part in range(args.streams):
-            plo, phi = (lo + sharding.shard_range(n_mine, part, args.streams)[0],
-                        lo + sharding.shard_range(n_mine, part, args.streams)[1])
+        for part in range(parts):
+            plo, phi = (lo + sharding.shard_range(n_mine, part, parts)[0],
+                        lo + sharding.shard_range(n_mine, part, parts)[1])
             batch = rd.Batch(level, args.width, args.height, max(phi - plo, 1))
             poses = sharding.pose_sweep(rd, built, phi - plo, args.width, args.height, first=plo)
             if args.time_varying:
@@ -317,15 +512,15 @@ def main():
                 lights = np.stack([built.lights_at(float(t)) for t in times]) if phi > plo else np.zeros((0, 256), np.uint8)
             else:
                 lights = built.lights_at(0.0)
-            tstream = torch.cuda.Stream() if args.streams > 1 else None
-            stream = tstream.cuda_stream if tstream is not None else None
-            if tstream is not None and all(tstream is not x for x in tstreams):
-                tstreams.append(tstream)
+            stream = tstreams[(li * parts + part) % len(tstreams)].cuda_stream if tstreams else None
             work.append((built, level, batch, poses, lights, stream))
-        if args.streams > 1:   # the whole pose range as ONE batch, for the single-stream pass after the timed region
-            poses = np.concatenate([w[3] for w in work[-args.streams:]])
-            lights = np.concatenate([w[4] for w in work[-args.streams:]]) if args.time_varying else built.lights_at(0.0)
-            work_full.append((built, level, rd.Batch(level, args.width, args.height, max(n_mine, 1)), poses, lights, None))
+        if args.streams > 1:   # the whole pose range as ONE batch on the default stream, for the single-stream pass after the timed region
+            if parts == 1:
+                work_full.append(work[-1][:5] + (None,))   # (the same batch)
+            else:
+                poses = np.concatenate([w[3] for w in work[-parts:]])
+                lights = np.concatenate([w[4] for w in work[-parts:]]) if args.time_varying else built.lights_at(0.0)
+                work_full.append((built, level, rd.Batch(level, args.width, args.height, max(n_mine, 1)), poses, lights, None))
 
     def barrier():
         torch.cuda.synchronize()
@@ -345,17 +540,31 @@ def main():
                 acc['visible_triangles'] = acc.get('visible_triangles', 0) + t['visible_triangles'] * t['renders']
                 acc['fixup_pixels'] = acc.get('fixup_pixels', 0) + t['fixup_pixels'] * t['renders']
 
-    def step(i, items=None):
+    # With several streams the timed region uses PLAIN renders: the four events a profiled render records are barriers between
+    # the kernels of its stream, and the per-kernel times of overlapped kernels mean nothing anyway (they come from the
+    # single-stream pass below).
+    timed_profiled = args.streams == 1
+
+    def step(i, items=None, profiled=True):
         for _built, _level, batch, poses, lights, stream in (work if items is None else items):
             if len(poses):
-                batch.render_profiled(poses, lights, stream=stream)
-        return i % 30 == 29   # (at most 64 profiled renders may be pending per batch)
+                (batch.render_profiled if profiled else batch.render)(poses, lights, stream=stream)
+        return profiled and i % 30 == 29   # (at most 64 profiled renders may be pending per batch)
 
     for i in range(args.warmup):
-        if step(i):
+        if step(i, None, timed_profiled):
             collect(None)
     collect(None)
     barrier()
+    if args.long > 0:   # --long: as many timed steps as fill that many seconds, from a calibration pass of K steps (every rank agrees)
+        t_w = time.perf_counter()
+        for i in range(args.steps):
+            if step(i, None, timed_profiled):
+                collect(None)
+        collect(None)
+        barrier()
+        est = sharding.max_over_ranks((time.perf_counter() - t_w) / args.steps, dist, 'cuda' if backend == 'nccl' else 'cpu')
+        args.steps = max(args.steps, int(np.ceil(1.05 * args.long / max(est, 1e-6))))
     # per-step spread: an event at the end of every step on every render stream (GPU time stamps; nothing waits for them)
     mark_streams = tstreams if tstreams else [torch.cuda.current_stream()]
     ev_start = torch.cuda.Event(enable_timing=True)
@@ -364,7 +573,7 @@ def main():
     t_start = time.perf_counter()
     acc = {'setup_ms': 0.0, 'raster_ms': 0.0, 'fragment_ms': 0.0}
     for i in range(args.steps):
-        flush = step(i)
+        flush = step(i, None, timed_profiled)
         marks = [torch.cuda.Event(enable_timing=True) for _ in mark_streams]
         for e, st in zip(marks, mark_streams):
             e.record(st)
@@ -404,7 +613,7 @@ def main():
         my_px_per_step = n_mine * frame_px * len(levels)
         frag = acc['fragment_ms'] / args.steps             # this rank's fragment-kernel time per step (all levels)
         achieved = my_px_per_step * ALG_READ_BYTES_PER_PIXEL / (frag * 1e-3) / 1e9 if frag > 0 else 0.0
-        traffic = frac_actual = valu = None
+        traffic = frac_actual = valu = pmc_source = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_fragment_latest.json')
         if os.path.exists(pmc) and world == 1:
             try:
@@ -413,8 +622,13 @@ def main():
                     traffic = rec.get('hbm_bytes_per_launch')
                     frac_actual = round(traffic / (frag * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                     valu = rec.get('valu')   # the VALU-issue roofline of the hot kernels (same passes: see tools/profile_collect.py)
+                    # REPLAYED, not measured by this run: counter passes cannot share a run with the timing (rocprofv3 serialises
+                    # the kernels); they are quoted only while the device sources are byte-identical to the ones they were taken on
+                    pmc_source = 'profiles/pmc_fragment_latest.json (replayed: rocprofv3 --pmc passes of %s on kernel sources %s, taken %s)' % (
+                        rec.get('workload'), rec.get('kernel_sources'), rec.get('taken', 'by tools/profile_round.sh'))
             except Exception:
                 traffic = None
+        paths = merge_path_stats([item[2] for item in (work_full or work)])   # of the last renders: which paths the workload took
         # BASELINE configs 2 / 4 / 5 in short, on the same box, same library, same timing scheme (N = 1 only): the headline's
         # scratch is released first
         other_lines = None
@@ -430,9 +644,20 @@ def main():
                 if key not in wads:
                     wads[key] = rd.Wad(synthetic.ensure_big_wad() if key else synthetic.ensure_wad(), synthetic.META_PATH)
                 try:
-                    other_lines.append(quick_line(rd, torch, sharding, wads[key], spec, spec.get('streams', max(args.streams, 1)) if args.streams > 1 else 1))
+                    ws = 1 if cli_streams == 1 else spec.get('streams', resolve_streams(0, len(spec['levels'])))   # (--streams 1: everything on one stream)
+                    line = quick_line(rd, torch, sharding, wads[key], spec, ws)
+                    if spec.get('share'):   # the strong-scaling share a one-GPU box can time (BASELINE config 4 is strong scaling)
+                        line['scaling_proxy'] = scaling_proxy(rd, torch, sharding, wads[key], spec, spec['share'], line)
+                    other_lines.append(line)
                 except Exception as e:  # noqa: BLE001  (a failing extra must not take the headline with it: it says so instead)
                     other_lines.append({'workload': spec['name'], 'error': repr(e)})
+        proxy = None
+        if world == 1 and args.share > 1:
+            for item in work + work_full:
+                item[2].close()
+            spec = dict(name=metric_label(args, levels), levels=levels, big=args.big, width=args.width, height=args.height, poses=args.poses, tv=args.time_varying)
+            proxy = scaling_proxy(rd, torch, sharding, wad, spec, args.share, {'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'streams': args.streams},
+                                  steps=max(8, min(args.steps, 20)))
         cpu = None
         if args.cpu_sample > 0 and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             from oracle import raster
@@ -493,7 +718,12 @@ def main():
                        'kernels_ms_from': ('the timed region (one stream)' if args.streams == 1 else
                                            'a single-stream pass after the timed region (the same poses as ONE batch, %d steps, one launch per kernel and step): '
                                            'with %d streams the kernels overlap, so their sum exceeds ms_per_step' % (args.steps, args.streams)),
-                       'streams': args.streams, **({'debug': args.debug} if args.debug else {}),
+                       'streams': args.streams,
+                       'stream_plan': ('%d sub-batches of the poses, one per stream' % parts) if len(levels) == 1 else
+                                      ('the %d levels alternate over the %d streams, %s' % (len(levels), args.streams, 'one batch each' if parts == 1 else '%d sub-batches each' % parts)),
+                       # which paths the renders took (rdoom_batch_path_stats of every batch's last render)
+                       'paths': paths,
+                       **({'debug': args.debug} if args.debug else {}),
                        'workload_key': workload_key(args, levels), 'measurement_key': measurement_key(args, levels),
                        'comparable_with_rounds_1_2': 'single_stream.value' if args.streams > 1 else 'value',
                        'kernel_sources': kernel_source_digest()},
@@ -507,7 +737,7 @@ def main():
                          # frac: SURVEY 8(d)'s 6 B/px; frac_layout_bytes: the 2 + 2 B/px this layout keeps per pixel (the quadrant
                          # table lets uniform quadrants skip even those); frac_actual_bytes: HBM traffic by the PMC counters
                          'frac_layout_bytes': round(achieved / HBM_PEAK_GBS * LAYOUT_READ_BYTES_PER_PIXEL / ALG_READ_BYTES_PER_PIXEL, 4),
-                         'traffic': traffic, 'frac_actual_bytes': frac_actual,
+                         'traffic': traffic, 'frac_actual_bytes': frac_actual, 'traffic_source': pmc_source,
                          # what binds the step: VALU issue, not HBM (PMC passes of tools/profile_round.sh on THESE kernel sources,
                          # null when none were taken): wave64 VALU instructions per pixel, issue cycles = SQ_ACTIVE_INST_VALU x 4 / 1024
                          # SIMDs, frac = issue cycles / kernel cycles (GRBM_GUI_ACTIVE / 8 XCDs), per hot kernel and for the step
@@ -515,6 +745,10 @@ def main():
             'other_workloads': other_lines,
             'cpu_baseline': cpu,
         }
+        if proxy is not None:
+            out['scaling_proxy'] = proxy
+        if args.long > 0:
+            out['long'] = {'asked_seconds': args.long, 'timed_seconds': round(elapsed, 3)}
         if single_elapsed is not None:   # the same work without the overlap: the step the per-kernel figures add up to
             out['single_stream'] = {'value': round(total_px / single_elapsed / 1e6, 1), 'unit': 'Mpixels/s',
                                     'ms_per_step': round(single_elapsed / args.steps * 1e3, 3)}

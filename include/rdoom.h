@@ -146,6 +146,18 @@ typedef struct rdoom_counters {
       num_sky_ceil_polys, num_decors, num_static_tris, num_sky_tris, num_sprite_tris, num_objects, num_lights;
 } rdoom_counters;
 
+/* Which paths the last render of a batch took (read back from the device after it): a workload whose poses overflow their
+ * tile lists is rasterised from the sorted list -- correct, and slow -- and nothing else would say so.  No reference counterpart. */
+typedef struct rdoom_path_stats {
+  uint32_t poses;                 /* of the last render */
+  uint32_t bins_overflowed_poses; /* poses whose tile lists did not fit (or a frame with too many tiles): rasterised from the sorted list */
+  uint64_t tiles;                 /* 64 x 64 tiles of those poses' frames */
+  uint64_t split_tiles;           /* tiles whose list (more than 64 entries) is stored per 32 x 32 quadrant */
+  uint64_t tile_entries;          /* sum of the tile lists' lengths (one per triangle and tile) */
+  uint64_t quadrants;             /* 32 x 32 quadrants that lie (partly) inside the frame */
+  uint64_t described_quadrants;   /* of those: all pixels show one record -- no visibility words stored or read */
+} rdoom_path_stats;
+
 const char *rdoom_last_error(void);
 
 /* ---- devices ------------------------------------------------------------------------------ */
@@ -158,7 +170,9 @@ rdoom_status rdoom_set_device(int32_t device);
 rdoom_status rdoom_level_create(const rdoom_level_desc *desc, rdoom_level **out_level);
 void rdoom_level_destroy(rdoom_level *level);
 
-/* allocates the device scratch for up to max_poses frames of width x height (width % 4 == 0) */
+/* allocates the device scratch for up to max_poses frames of width x height -- any size up to 16384 on a side, as the
+ * reference's --resolution WxH (src/main.rs:41).  Rows of the device framebuffer are rdoom_batch_framebuffer_pitch bytes
+ * apart: the width itself when it is a multiple of 4, else the next multiple of 8. */
 rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32_t height, uint32_t max_poses,
                                 rdoom_batch **out_batch);
 void rdoom_batch_destroy(rdoom_batch *batch);
@@ -190,15 +204,23 @@ rdoom_status rdoom_batch_render_objects(rdoom_batch *batch, const rdoom_pose *po
                                         const float *object_modelviews, uint32_t n_objects);
 /* 1 + the largest rdoom_draw.object_id of the level */
 rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out);
-/* Waits for the batch's last render and returns ITS status: the asynchronous rdoom_batch_render cannot report what only
+/* Waits for the batch's last render -- on the stream it was queued on; work of other batches on other streams is not waited
+ * for -- and returns ITS status: the asynchronous rdoom_batch_render cannot report what only
  * the device finds out (today: the alpha-leak fixup list overflowing, which would leave leaked transparent texels in
  * the frames).  Consumers of rdoom_batch_framebuffer_device call this -- or any of the rdoom_batch_read_* -- before
  * trusting the frames; glFinish is the nearest reference counterpart. */
 rdoom_status rdoom_batch_finish(rdoom_batch *batch);
 
-/* device pointer to the n_poses*height*width palette-index framebuffers of the last render */
+/* waits for the batch's last render like rdoom_batch_finish, then counts (see rdoom_path_stats) */
+rdoom_status rdoom_batch_path_stats(rdoom_batch *batch, rdoom_path_stats *out);
+
+/* device pointer to the n_poses palette-index framebuffers of the last render: frame i starts at byte i * height * pitch,
+ * row y of it (row 0 = the bottom row, as glReadPixels) at y * pitch, `width` bytes of pixels, then padding */
 rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **out_device_ptr);
-/* glReadPixels analogue: synchronises, copies frames [first, first+count) to host memory */
+/* bytes between consecutive rows of the device framebuffer (== width when width % 4 == 0) */
+rdoom_status rdoom_batch_framebuffer_pitch(const rdoom_batch *batch, uint32_t *out_pitch);
+/* glReadPixels analogue: waits for the batch's last render (on its stream -- not for the device), copies frames
+ * [first, first+count) to host memory, tightly packed (width bytes per row) */
 rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *batch, uint32_t first, uint32_t count, uint8_t *host_out);
 /* Debug / test facility: capture the winning primitive id per pixel (global triangle index in draw order,
  * 0xFFFFFFFF = none) on the following renders, then read it back.  No GL counterpart. */
@@ -217,7 +239,8 @@ rdoom_status rdoom_selftest_fastmath(uint64_t out_counts[8]);
  * shaped but EQUIVALENT path through the kernels -- the image must not change -- so that the rarely taken ones can be
  * forced (tests/test_gpu_debug_paths.py).  Process-wide; read when a batch is created ("vis32", "entry_cap") or
  * rendered (the rest).  Names: no_bins, entry_cap, vis32, leak_mod, frag_nq, frag_bw, frag_chunk, bin_threads,
- * no_cover, raster_stats, no_qtab, keep_vis, qpath, no_split (rust-doom_amd/csrc/common.hpp: DebugOptions); "reset" restores the defaults. */
+ * no_cover, no_pair, raster_stats, no_qtab, keep_vis, qpath, no_split (rust-doom_amd/csrc/common.hpp: DebugOptions); "reset" restores the
+ * defaults. */
 rdoom_status rdoom_debug_set(const char *name, int32_t value);
 
 /* ---- loader + builder: the `wad` crate and `game::level` static-geometry builder ----------- */

@@ -61,6 +61,11 @@ class Timings(ctypes.Structure):
                 ('fixup_pixels', ctypes.c_uint64)]
 
 
+class PathStats(ctypes.Structure):
+    _fields_ = [('poses', ctypes.c_uint32), ('bins_overflowed_poses', ctypes.c_uint32), ('tiles', ctypes.c_uint64), ('split_tiles', ctypes.c_uint64),
+                ('tile_entries', ctypes.c_uint64), ('quadrants', ctypes.c_uint64), ('described_quadrants', ctypes.c_uint64)]
+
+
 class HostTimings(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in ('open_ms', 'textures_ms', 'level_lumps_ms', 'atlases_ms', 'analysis_ms', 'walk_ms')]
 
@@ -81,7 +86,7 @@ API_SYMBOLS = [
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
     'rdoom_built_counters', 'rdoom_built_lights_at', 'rdoom_built_start', 'rdoom_built_floor_centroids',
     'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_debug_set', 'rdoom_wad_walk', 'rdoom_wad_build_level_chained', 'rdoom_batch_render_objects', 'rdoom_level_num_objects', 'rdoom_batch_enable_primitive_ids',
-    'rdoom_wad_timings', 'rdoom_built_timings', 'rdoom_pose_from_player']
+    'rdoom_wad_timings', 'rdoom_built_timings', 'rdoom_pose_from_player', 'rdoom_batch_framebuffer_pitch', 'rdoom_batch_path_stats']
 
 _lib = None
 
@@ -501,6 +506,18 @@ class Batch:
         p = ctypes.c_void_p()
         _check(lib().rdoom_batch_framebuffer_device(self._h, ctypes.byref(p)))
         return p.value
+
+    def path_stats(self):
+        """rdoom_batch_path_stats: which paths the last render took (overflowed poses, split tile lists, described quadrants)"""
+        s = PathStats()
+        _check(lib().rdoom_batch_path_stats(self._h, ctypes.byref(s)))
+        return {n: getattr(s, n) for n, _ in PathStats._fields_}
+
+    def framebuffer_pitch(self):
+        """bytes between rows of the device framebuffer (the width, or the next multiple of 8 when width % 4 != 0)"""
+        n = ctypes.c_uint32()
+        _check(lib().rdoom_batch_framebuffer_pitch(self._h, ctypes.byref(n)))
+        return n.value
 
     def read_framebuffer(self, first=0, count=None):
         count = self.last_n - first if count is None else count

@@ -24,6 +24,7 @@ struct DebugOptions {
   int no_qtab = 0;       // the fragment kernel ignores the rasteriser's quadrant table (every wave reads its visibility words)
   int qpath = 0;         // the whole-quadrant fragment kernel runs first (off by default: measured slower)
   int keep_vis = 0;      // the rasteriser writes the visibility words of every quadrant, also of those the table describes
+  int no_pair = 0;       // no two-entry shortcut in the rasteriser (a quadrant shared by two triangles along a common edge takes the general pass)
   int no_split = 0;      // no per-quadrant lists for tiles with more than 64 entries: the rasteriser re-gathers such a tile's whole list for every quadrant
   int raster_stats = 0;  // census of the rasteriser's paths on stderr (instrumented instantiation: slower)
 };

@@ -283,12 +283,17 @@ bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint
     lds = attr.sharedSizeBytes + 1;
     slot.store(lds, std::memory_order_relaxed);
   }
-  if ((lds - 1) + sizeof(uint32_t) * bin_tiles > 65536u || (uint32_t)(tiles_x * tiles_y) > MAX_TILES) return false;
+  // (the dynamic segment as it is REQUESTED: a counter per tile, two more with split lists, and 8 bytes that keep the 64-bit
+  // words of the split lists' counters aligned -- the same number in the budget test and in the launch)
+  auto dyn_bytes = [&](bool with_split) { return (with_split ? 3 : 1) * sizeof(uint32_t) * (size_t)bin_tiles + 8u; };
+  if ((lds - 1) + dyn_bytes(false) > 65536u || (uint32_t)(tiles_x * tiles_y) > MAX_TILES) return false;
   // split lists need two more counters per tile (frames beyond ~4 000 tiles -- 5K and up -- keep whole-tile lists)
-  const bool split = want_split && (lds - 1) + 3 * sizeof(uint32_t) * bin_tiles <= 65536u;
+  const bool split = want_split && (lds - 1) + dyn_bytes(true) <= 65536u;
   *used_split = split;
-  hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bt), (split ? 3 : 1) * sizeof(uint32_t) * bin_tiles + 8, st, recs, sorted, counts, cap, tiles_x,
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bt), dyn_bytes(split), st, recs, sorted, counts, cap, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, hits, overflow, split ? 1u : 0u);
+  if (hipGetLastError() != hipSuccess) return false;  // not launched: the caller flags every pose as "bins incomplete"
   return true;
 }
 

@@ -865,7 +865,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
                                                     const uint4 *__restrict__ sorted,
                                                     const uint32_t *__restrict__ counts, uint32_t cap,
-                                                    const PoseConst *__restrict__ poses, int width, int height,
+                                                    const PoseConst *__restrict__ poses, int width, int pitch, int height,
                                                     int tiles_x, int tiles_y, const uint2 *__restrict__ tile_hdr,
                                                     const uint32_t *__restrict__ entries, uint32_t entry_cap,
                                                     const uint32_t *__restrict__ overflow,
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
   for (uint32_t item = wave_id; item < total; item += n_waves) {
     const uint2 it = fix_list[item];
     const uint32_t pose = it.x, pix = it.y;
-    const int iy = (int)(pix / (uint32_t)width), ix = (int)(pix - (uint32_t)iy * (uint32_t)width);
+    const int iy = (int)(pix / (uint32_t)pitch), ix = (int)(pix - (uint32_t)iy * (uint32_t)pitch);  // (queued as row * pitch + column)
     const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
     const TriRec *prec = recs + (size_t)pose * cap;
     const bool binned = overflow[pose] == 0u;
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
       }
     }
     if (lane == 0) {
-      const size_t o = ((size_t)pose * (size_t)height + (size_t)iy) * (size_t)width + (size_t)ix;
+      const size_t o = ((size_t)pose * (size_t)height + (size_t)iy) * (size_t)pitch + (size_t)ix;
       uint32_t colour = 0;
       if (best_rec != NONE) {
         const ShadeRec sh = prec[best_rec].s;
@@ -953,12 +953,12 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
 
 size_t fragment_const_bytes() { return sizeof(FragConst); }
 
-FragmentPlan plan_fragment(int width, int height, bool have_qtab) {
+FragmentPlan plan_fragment(int width, int pitch, int height, bool have_qtab) {
   (void)height;
   const rdoom::DebugOptions dbg = rdoom::debug_options();  // test hooks: equivalent paths, same image
   FragmentPlan p{};
   p.leak_mod = (uint32_t)std::max(0, dbg.leak_mod);
-  p.nq = (dbg.frag_nq == 2 && width % 8 == 0) ? 2 : 1;  // quads per lane: two when rows divide into 8-pixel runs
+  p.nq = (dbg.frag_nq == 2 && pitch % 8 == 0) ? 2 : 1;  // quads per lane: two when rows (of `pitch` pixels) divide into 8-pixel runs
   p.bwl = (uint32_t)std::min(6, std::max(0, dbg.frag_bw));  // log2(units per block row)
   p.chunk = dbg.frag_chunk > 0 ? (uint32_t)dbg.frag_chunk : (uint32_t)FRAG_CHUNK;
   // the quadrant table serves blocks that lie inside one 32 x 32 quadrant, or inside two side by side
@@ -972,20 +972,21 @@ FragmentPlan plan_fragment(int width, int height, bool have_qtab) {
   // -- an alternative path, OFF by default (the hook "qpath" switches it on): measured in round 4, the two kernels together are
   // 10 % slower than fragment_kernel alone (the quadrant kernel needs 211 VALU instructions per 8-pixel run
   // where fragment_kernel's wave-uniform body needs 275, and what is left for fragment_kernel are the expensive blocks)
-  p.quadrant_path = p.qtab_mode != 0u && p.leak_mod == 0u && dbg.qpath && width % 8 == 0;
+  p.quadrant_path = p.qtab_mode != 0u && p.leak_mod == 0u && dbg.qpath && width % 8 == 0 && pitch == width;
   return p;
 }
 
 rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                              const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,
-                             int width, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
+                             int width, int pitch, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
                              const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
                              bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
                              uint2 *fix_list, uint32_t fix_cap, uint32_t *qtab, void *d_frag_const,
                              bool *frag_const_ready, const FragmentPlan &plan) {
   const uint32_t n = n_poses;
+  // W: the frame (sky ndc); rows of visibility words and framebuffer bytes are `pitch` pixels apart (a multiple of 4, W <= pitch < W + 8)
   const int W = width, H = height;
-  const uint32_t qpr = (uint32_t)W / 4u, qpp = qpr * (uint32_t)H;
+  const uint32_t qpr = (uint32_t)pitch / 4u, qpp = qpr * (uint32_t)H;
   if (qpp >= (1u << 24)) return rdoom::fail(RDOOM_BAD_ARG, "frame too large");
   // multiply-high divisor for idx / qpr, idx < 2^24 (checked exhaustively at the only places it can fail)
   if (qpr < 2) return rdoom::fail(RDOOM_BAD_ARG, "width must be at least 8");
@@ -997,7 +998,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
     const uint32_t lo = k * qpr - 1, hi = k * qpr;
     if ((uint32_t)(((uint64_t)lo * div_m) >> 32) >> div_sh != k - 1 ||
         (hi < qpp && (uint32_t)(((uint64_t)hi * div_m) >> 32) >> div_sh != k))
-      return rdoom::fail(RDOOM_BAD_ARG, "internal: fast_div constants invalid for width %d", W);
+      return rdoom::fail(RDOOM_BAD_ARG, "internal: fast_div constants invalid for row pitch %d", pitch);
   }
   const uint32_t debug_leak_mod = plan.leak_mod;
   const int nq = plan.nq;
@@ -1033,7 +1034,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
   hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(64 * FRAG_WAVES), 0, st, static_cast<const FragConst *>(d_frag_const), lv.texels,
                      lv.colormap, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp, qpr, wbpr, wbpp, bwl, W, H, fb, debug_leak_mod, qtab,
                      qtab_mode, (uint32_t)tiles_x, (uint32_t)(tiles_x * tiles_y));
-  hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, H, tiles_x, tiles_y,
+  hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, pitch, H, tiles_x, tiles_y,
                      tile_hdr, entries, entry_cap, overflow, fix_count, fix_list, fix_cap, vis, vis16 ? 1u : 0u, prim_out, fb,
                      fix_count + 1);
 #ifdef RDOOM_FRAG_STATS

@@ -52,11 +52,12 @@ struct FragmentPlan {
   // fragment_quadrant_kernel shades the described quadrants whose record qualifies before fragment_kernel runs
   bool quadrant_path;
 };
-FragmentPlan plan_fragment(int width, int height, bool have_qtab);
+FragmentPlan plan_fragment(int width, int pitch, int height, bool have_qtab);
 // Kernels 3 + 4: fragment kernel -> palette indices, then the alpha-leak fixup (fragment.hip)
 rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                              const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,
-                             int width, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
+                             int width, int pitch,  // the frame's width; pixels between rows of visibility words / framebuffer bytes
+                             int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
                              const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
                              bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
                              uint2 *fix_list, uint32_t fix_cap, uint32_t *qtab, void *d_frag_const,

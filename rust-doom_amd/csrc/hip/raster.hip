@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
                               ((c4.y & RASTER_MASKED_INTERIOR) == 0u);
           const bool p0 = n0 > 0.0f, p1 = n1 > 0.0f, p2 = n2 > 0.0f;
           const bool cov = common & p0 & p1 & p2;
-          myqb |= (cov && !no_cover) ? (16u << qi) : 0u;  // no_cover: test hook
+          myqb |= (cov && !(no_cover & 1u)) ? (16u << qi) : 0u;  // no_cover bit 0: test hook "no_cover"
           covx |= ((common & p1 & p2) ? (1u << qi) : 0u) | ((common & p0 & p2) ? (16u << qi) : 0u) | ((common & p0 & p1) ? (256u << qi) : 0u);
         }
         {
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
           auto edge_hash = [&](uint32_t a, uint32_t b, uint32_t c) {
             return mag(a) ^ __builtin_amdgcn_alignbit(mag(b), mag(b), 21) ^ __builtin_amdgcn_alignbit(mag(c), mag(c), 11);
           };
-          whash[wave][lane] = make_uint4(edge_hash(c0.x, c0.y, c0.z), edge_hash(c0.w, c1.x, c1.y), edge_hash(c1.z, c1.w, c2.x), no_cover ? 0u : covx);
+          whash[wave][lane] = make_uint4(edge_hash(c0.x, c0.y, c0.z), edge_hash(c0.w, c1.x, c1.y), edge_hash(c1.z, c1.w, c2.x), no_cover ? 0u : covx);  // (bit 1 alone: test hook "no_pair")
         }
         dnq0 = dn[0], dnq1 = dn[1], dnq2 = dn[2], dnq3 = dn[3];
         myrq = myrec | (myqb << 24);
@@ -680,6 +680,16 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       best_d[k] = NONE;
       best_r[k] = NONE;
     }
+    // A frame height that is not a multiple of 4: the bottom block row of the frame has pixel rows below it.  They start at depth 0
+    // -- nothing is nearer, so they never win (a depth equal to 0 replays through the general rule, whose bounding-box test
+    // excludes them) -- instead of "none", which kept such a lane's farthest depth, and with it the wave's, at "none" for the
+    // whole pass: no early-z on the bottom quadrant row.  (uniform branch: only quadrants that cross the frame's bottom edge)
+    const bool rows_below = qy0 + 32 > height;
+    if (rows_below) {
+#pragma unroll
+      for (int ry = 1; ry < 4; ry++)
+        if (by + ry >= height && by < height) best_d[4 * ry] = best_d[4 * ry + 1] = best_d[4 * ry + 2] = best_d[4 * ry + 3] = 0u;
+    }
     // max of best_d: the farthest depth this lane still holds.  A lane whose block lies outside the frame (partial tiles:
     // the bottom row at 1080 = 16 * 64 + 56) stores nothing and must not keep the wave-wide farthest depth at "none"
     uint32_t lane_far = ((bx >= width) | (by >= height)) ? 0u : NONE;
@@ -787,12 +797,20 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
     if (qtab && had_cover) {  // (one winner needs a triangle that covers the quadrant: without one the check is skipped)
       const uint32_t rf = (uint32_t)__builtin_amdgcn_readfirstlane((int)best_r[0]);
       uint32_t lo = best_r[0], hi = best_r[0];  // (three-operand min / max: 16 instructions for the 16 winners)
+      if (!rows_below) {
 #pragma unroll
-      for (int k = 1; k < 15; k += 2) {
-        lo = min(lo, min(best_r[k], best_r[k + 1]));
-        hi = max(hi, max(best_r[k], best_r[k + 1]));
+        for (int k = 1; k < 15; k += 2) {
+          lo = min(lo, min(best_r[k], best_r[k + 1]));
+          hi = max(hi, max(best_r[k], best_r[k + 1]));
+        }
+        lo = min(lo, best_r[15]), hi = max(hi, best_r[15]);
+      } else {  // the pixel rows below the frame (winner "none" for ever) do not count: the table speaks about the pixels of the frame
+#pragma unroll
+        for (int k = 1; k < 16; k++) {
+          const uint32_t v = (by + (k >> 2) >= height) ? rf : best_r[k];
+          lo = min(lo, v), hi = max(hi, v);
+        }
       }
-      lo = min(lo, best_r[15]), hi = max(hi, best_r[15]);
       const bool outside_lane = (bx >= width) | (by >= height);
       if (rf != NONE && __all(outside_lane | ((lo == rf) & (hi == rf)))) described = rf;
     }
@@ -860,7 +878,7 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
   };
   auto rk = split_lists ? pick2(std::true_type{}) : pick2(std::false_type{});
   hipLaunchKernelGGL(rk, dim3((uint32_t)tiles_x * 8u, (uint32_t)tiles_y, groups), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
-                     tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, dbg.no_cover ? 1u : 0u,
+                     tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, (dbg.no_cover ? 1u : 0u) | (dbg.no_pair ? 2u : 0u),
                      qtab, d_stats);
 #ifdef RDOOM_CENSUS_TWO
   {

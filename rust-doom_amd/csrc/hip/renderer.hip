@@ -24,6 +24,19 @@ namespace {
 bool is_pow2(uint32_t x) { return x != 0 && (x & (x - 1)) == 0; }
 }  // namespace
 
+// Host-side section timers of rdoom_batch_render (tools/variant.sh NAME renderer -DRDOOM_HOST_TIMERS; never in the shipped
+// library): where does the host's time per render go?  Sums are printed when a batch is destroyed.
+#ifdef RDOOM_HOST_TIMERS
+#include <chrono>
+static double g_host_t[12];
+static unsigned long long g_host_n;
+#define HT_DECL auto ht_last = std::chrono::steady_clock::now();
+#define HT_MARK(i) do { const auto n_ = std::chrono::steady_clock::now(); g_host_t[i] += std::chrono::duration<double, std::micro>(n_ - ht_last).count(); ht_last = n_; } while (0)
+#else
+#define HT_DECL
+#define HT_MARK(i) do { } while (0)
+#endif
+
 struct rdoom_level {
   int device = 0;
   DeviceLevelView view{};
@@ -35,6 +48,11 @@ struct rdoom_level {
 struct rdoom_batch {
   const rdoom_level *level = nullptr;
   uint32_t width = 0, height = 0, max_poses = 0, cap = 0, last_n = 0;
+  // Row pitch, in pixels, of the visibility words, primitive ids and framebuffers: the width itself when it is a multiple of 4
+  // (every size the kernels were written for), else the next multiple of 8 -- the reference takes any --resolution WxH
+  // (src/main.rs:41).  The frame's geometry (viewport, bounding boxes, sky ndc) uses `width`; the padding columns are never
+  // covered (S6 clamps every bounding box to the frame) and never read back.
+  uint32_t pitch = 0;
   PoseConst *d_poses = nullptr;
   TriRec *d_recs = nullptr;   // max_poses x cap records in near-to-far order (setup -> bin, raster, fragment)
   uint32_t *d_visible = nullptr;  // max_poses x cap: the visible triangles of each pose (cull kernel -> set-up kernel)
@@ -54,13 +72,24 @@ struct rdoom_batch {
   uint32_t *d_qtab = nullptr;  // per (pose, tile, quadrant): the record every pixel of the quadrant shows, or NONE (rasteriser -> fragment kernel)
   uint32_t *d_ghist = nullptr;  // counting sort of the set-up: per pose, one counter per depth bucket
   uint8_t *d_fb = nullptr;
-  PoseConst *h_poses = nullptr;  // pinned staging for the per-pose constants
-  ObjectConst *d_objects = nullptr, *h_objects = nullptr;  // max_poses x n_objects, allocated on first use
+  // Pinned staging for the per-pose constants, TWO deep: a render waits for the H2D copy of the render before the previous
+  // one, not for the previous one's -- with one buffer the host could not queue a render before the stream had reached the last
+  // render's copy, and a host thread that feeds several batches on several streams stalled on each in turn (the 1/8 share of
+  // BASELINE config 4, nine levels x small batches, ran SLOWER on two streams than on one).
+  static constexpr uint32_t STAGES = 2;
+  PoseConst *h_poses[STAGES] = {nullptr, nullptr};
+  ObjectConst *d_objects = nullptr, *h_objects[STAGES] = {nullptr, nullptr};  // max_poses x n_objects, allocated on first use
+  uint32_t stage = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   static constexpr uint32_t RING = 64;  // renders whose per-kernel events may be pending (rdoom_batch_render_profiled)
   hipEvent_t ring[RING][4] = {};
   uint32_t ring_n = 0, ring_poses = 0;
-  hipEvent_t ev_copy = nullptr;  // H2D of h_poses finished: staging may be rewritten
+  hipEvent_t ev_copy[STAGES] = {nullptr, nullptr};  // H2D of h_poses[i] finished: that staging buffer may be rewritten
+  // The end of the last render on ITS stream, and a stream of the batch's own for read-backs: rdoom_batch_finish and the
+  // rdoom_batch_read_* wait for this batch's work only, never for the device -- another host thread's render on another
+  // stream (one host thread per GPU or stream) does not delay them.
+  hipEvent_t ev_done = nullptr;
+  hipStream_t copy_stream = nullptr;
   bool want_prim = false;
   bool vis16 = false;  // record indices fit 16 bits: visibility words are u16
   float *d_ndc = nullptr;  // (ix + 0.5) / (width / 2) - 1 for every column, then (iy + 0.5) / (height / 2) - 1 for every row
@@ -71,9 +100,22 @@ struct rdoom_batch {
 static hipError_t bind_device(const rdoom_batch *b) { return hipSetDevice(b->level->device); }
 
 // What only the device finds out about a render: read after a synchronisation, reported as a status.
+// Device -> host over the batch's own stream, after the batch's last render (and nothing else) has finished.  rows > 1: a
+// strided source (pitch_bytes between rows), tightly packed at the destination.
+static hipError_t read_back(const rdoom_batch *b, void *dst, const void *src, size_t row_bytes, size_t rows = 1, size_t pitch_bytes = 0) {
+  hipError_t e = hipStreamWaitEvent(b->copy_stream, b->ev_done, 0);  // (an event never recorded counts as complete)
+  if (e != hipSuccess) return e;
+  if (rows <= 1 || pitch_bytes == row_bytes)
+    e = hipMemcpyAsync(dst, src, row_bytes * (rows ? rows : 1), hipMemcpyDeviceToHost, b->copy_stream);
+  else
+    e = hipMemcpy2DAsync(dst, row_bytes, src, pitch_bytes, row_bytes, rows, hipMemcpyDeviceToHost, b->copy_stream);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(b->copy_stream);
+}
+
 static rdoom_status device_flags(const rdoom_batch *b, uint32_t *out_fixups = nullptr) {
   uint32_t fix[3] = {0, 0, 0};
-  HIP_TRY(hipMemcpy(fix, b->d_fix_count, sizeof fix, hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(b, fix, b->d_fix_count, sizeof fix));
   if (out_fixups) *out_fixups = fix[0];
   if (fix[1]) return rdoom::fail(RDOOM_BAD_LEVEL, "alpha-leak fixup list overflow (%u pixels)", fix[0]);
   if (fix[2]) return rdoom::fail(RDOOM_HIP_ERROR, "internal: set-up and cull kernels disagree about a triangle (build flags changed?)");
@@ -323,6 +365,17 @@ static rdoom_status level_create_impl(const rdoom_level_desc *d, rdoom_level **o
 
 void rdoom_batch_destroy(rdoom_batch *b) {
   if (!b) return;
+#ifdef RDOOM_HOST_TIMERS
+  if (g_host_n) {
+    static const char *names[12] = {"wait for the staging buffer", "per-pose constants", "H2D + event", "flag memset + set-up launches", "binning launch", "rasteriser launch",
+                                    "fragment + fixup launches", "closing event", "", "", "", ""};
+    fprintf(stderr, "[host timers] %llu renders, microseconds per render:", g_host_n);
+    for (int k = 0; k < 8; k++) fprintf(stderr, "  %s %.1f", names[k], g_host_t[k] / (double)g_host_n);
+    fprintf(stderr, "\n");
+    g_host_n = 0;
+    for (auto &t : g_host_t) t = 0;
+  }
+#endif
   for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_visible, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries, (void *)b->d_hits,
                   (void *)b->d_overflow, (void *)b->d_ghist, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb, (void *)b->d_qtab, b->d_frag_const})
@@ -332,9 +385,14 @@ void rdoom_batch_destroy(rdoom_batch *b) {
   for (auto &slot : b->ring)
     for (auto &e : slot)
       if (e) (void)hipEventDestroy(e);
-  if (b->ev_copy) (void)hipEventDestroy(b->ev_copy);
-  if (b->h_poses) (void)hipHostFree(b->h_poses);
-  if (b->h_objects) (void)hipHostFree(b->h_objects);
+  for (auto &e : b->ev_copy)
+    if (e) (void)hipEventDestroy(e);
+  if (b->ev_done) (void)hipEventDestroy(b->ev_done);
+  if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
+  for (auto &h : b->h_poses)
+    if (h) (void)hipHostFree(h);
+  for (auto &h : b->h_objects)
+    if (h) (void)hipHostFree(h);
   if (b->d_ndc) (void)hipFree(b->d_ndc);
   if (b->d_objects) (void)hipFree(b->d_objects);
   delete b;
@@ -344,19 +402,19 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
                                 rdoom_batch **out_batch) {
   if (!level || !out_batch) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   *out_batch = nullptr;
-  if (width == 0 || height == 0 || max_poses == 0 || width % 4 != 0 || width > 16384 || height > 16384)
-    return rdoom::fail(RDOOM_BAD_ARG, "bad frame size %ux%u (width must be a multiple of 4) or max_poses %u", width,
-                       height, max_poses);
+  if (width == 0 || height == 0 || max_poses == 0 || width > 16384 || height > 16384)
+    return rdoom::fail(RDOOM_BAD_ARG, "bad frame size %ux%u (1..16384 on a side) or max_poses %u", width, height, max_poses);
   HIP_TRY(hipSetDevice(level->device));  // the batch lives on the level's device, whatever the caller's current one is
   rdoom_batch *b = new rdoom_batch;
   b->level = level;
   b->width = width;
   b->height = height;
+  b->pitch = std::max(8u, width % 4u == 0u ? width : ((width + 7u) & ~7u));
   b->max_poses = max_poses;
   b->cap = level->ntri ? level->ntri : 1;
   const rdoom::DebugOptions &dbg = rdoom::debug_options();
   b->vis16 = b->cap < 0xFFFFu && !dbg.vis32;
-  const size_t npx = (size_t)width * height * max_poses;
+  const size_t npx = (size_t)b->pitch * height * max_poses;
   hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_visible, sizeof(uint32_t) * (size_t)b->cap * max_poses);
@@ -365,7 +423,10 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   // tile-list entries per pose; beyond it the pose is rasterised from its sorted list (slow: every tile scans every visible
   // triangle).  A long tile's list is stored per quadrant (bin.hip), an entry once per quadrant it touches, so the array is
   // sized generously -- never beyond what the level could ever need: every triangle in every quadrant of every tile
-  b->entry_cap = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(131072u, 64u * b->n_tiles), (uint64_t)b->cap * b->n_tiles * 4u + 8u * (uint64_t)b->n_tiles);
+  // (the floor scales with the frame: 256 entries per tile, at least 16 384 -- 131 072 for the 510 tiles of 1080p as before,
+  // 16 384 instead of 131 072 for the 20 tiles of 320 x 200, whose 8 192-pose batches had 12.9 GB of binning scratch)
+  b->entry_cap = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(std::max<uint32_t>(16384u, 256u * b->n_tiles), 64u * b->n_tiles),
+                                              (uint64_t)b->cap * b->n_tiles * 4u + 8u * (uint64_t)b->n_tiles);
   b->entry_cap = (b->entry_cap + 3u) & ~3u;
   if (dbg.entry_cap > 0) b->entry_cap = (uint32_t)dbg.entry_cap;  // tests: force that fallback
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_tile_hdr, sizeof(uint2) * (size_t)b->n_tiles * max_poses);
@@ -384,7 +445,9 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   // table is self-consistent for every reader)
   if (e == hipSuccess) e = hipMemset(b->d_qtab, 0xFF, sizeof(uint32_t) * 4u * (size_t)b->n_tiles * max_poses);
   if (e == hipSuccess) {  // sky.frag:13's ndc per column / row, same two operations as the per-pixel form
-    std::vector<float> ndc(width + height);
+    // (a run of sky that ends in the padding columns of a padded row pitch reads up to 7 values past the columns: row values, or
+    // the zeros the table is extended by -- colours of pixels nobody reads)
+    std::vector<float> ndc(std::max(width + height, b->pitch), 0.0f);
     for (uint32_t i = 0; i < width; i++) ndc[i] = ((float)i + 0.5f) / (0.5f * (float)width) - 1.0f;
     for (uint32_t i = 0; i < height; i++) ndc[width + i] = ((float)i + 0.5f) / (0.5f * (float)height) - 1.0f;
     e = hipMalloc((void **)&b->d_ndc, sizeof(float) * ndc.size());
@@ -392,8 +455,12 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   }
   for (auto &ev : b->ev)
     if (e == hipSuccess) e = hipEventCreate(&ev);
-  if (e == hipSuccess) e = hipEventCreate(&b->ev_copy);
-  if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_poses, sizeof(PoseConst) * max_poses, hipHostMallocDefault);
+  for (auto &ev : b->ev_copy)
+    if (e == hipSuccess) e = hipEventCreate(&ev);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev_done);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking);
+  for (auto &h : b->h_poses)
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h, sizeof(PoseConst) * max_poses, hipHostMallocDefault);
   if (e != hipSuccess) {
     rdoom_batch_destroy(b);
     return rdoom::fail(e == hipErrorOutOfMemory ? RDOOM_OOM : RDOOM_HIP_ERROR, "batch allocation failed: %s",
@@ -419,14 +486,21 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   HIP_TRY(hipSetDevice(lv->device));  // level, scratch and kernels on one device (several GPUs driven from one process)
   if (object_modelviews && n_objects < lv->n_objects)
     return rdoom::fail(RDOOM_BAD_ARG, "n_objects %u but the level draws objects 0..%u", n_objects, lv->n_objects - 1);
-  HIP_TRY(hipEventSynchronize(b->ev_copy));  // previous render's H2D must be done before restaging
+  HT_DECL
+  const uint32_t sg = b->stage;  // this render's staging buffers: the H2D copy that last read them is two renders back
+  b->stage = (sg + 1u) % rdoom_batch::STAGES;
+  HIP_TRY(hipEventSynchronize(b->ev_copy[sg]));
+  HT_MARK(0);
+  PoseConst *h_poses = b->h_poses[sg];
   if (object_modelviews) {
     const size_t count = (size_t)b->max_poses * lv->n_objects;
     if (!b->d_objects) HIP_TRY(hipMalloc((void **)&b->d_objects, sizeof(ObjectConst) * count));
-    if (!b->h_objects) HIP_TRY(hipHostMalloc((void **)&b->h_objects, sizeof(ObjectConst) * count, hipHostMallocDefault));
+    for (auto &h : b->h_objects)
+      if (!h) HIP_TRY(hipHostMalloc((void **)&h, sizeof(ObjectConst) * count, hipHostMallocDefault));
+    ObjectConst *h_objects = b->h_objects[sg];
     for (uint32_t p = 0; p < n; p++)
       for (uint32_t o = 0; o < lv->n_objects; o++) {
-        ObjectConst &oc = b->h_objects[(size_t)p * lv->n_objects + o];
+        ObjectConst &oc = h_objects[(size_t)p * lv->n_objects + o];
         const float *M = object_modelviews + ((size_t)p * n_objects + o) * 16;
         mat_mul_v1(poses[p].projection, M, oc.pm);
         std::memcpy(oc.mv, M, sizeof oc.mv);
@@ -436,7 +510,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
       }
   }
   for (uint32_t p = 0; p < n; p++) {  // V1: PM = P * M, plain multiply/add, left to right
-    PoseConst &pc = b->h_poses[p];
+    PoseConst &pc = h_poses[p];
     const float *P = poses[p].projection, *M = poses[p].modelview;
     mat_mul_v1(P, M, pc.pm);
     std::memcpy(pc.mv, M, sizeof pc.mv);
@@ -448,6 +522,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     std::memcpy(pc.lights, lights + (size_t)p * lights_stride, 256);
   }
   b->last_n = n;
+  HT_MARK(1);
   hipEvent_t *ev = b->ev;  // the four marks of this render: the batch's own, or a slot of the ring when nobody waits
   if (profiled) {
     if (b->ring_n == rdoom_batch::RING) return rdoom::fail(RDOOM_BAD_ARG, "%u profiled renders pending: collect the timings first", b->ring_n);
@@ -457,18 +532,20 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   }
   const bool marks = tm || profiled;
   if (marks) HIP_TRY(hipEventRecord(ev[0], st));
-  HIP_TRY(hipMemcpyAsync(b->d_poses, b->h_poses, sizeof(PoseConst) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(b->d_poses, h_poses, sizeof(PoseConst) * n, hipMemcpyHostToDevice, st));
   if (object_modelviews)
-    HIP_TRY(hipMemcpyAsync(b->d_objects, b->h_objects, sizeof(ObjectConst) * (size_t)n * lv->n_objects,
+    HIP_TRY(hipMemcpyAsync(b->d_objects, b->h_objects[sg], sizeof(ObjectConst) * (size_t)n * lv->n_objects,
                            hipMemcpyHostToDevice, st));
-  HIP_TRY(hipEventRecord(b->ev_copy, st));
-  const int W = (int)b->width, H = (int)b->height;
+  HIP_TRY(hipEventRecord(b->ev_copy[sg], st));
+  HT_MARK(2);
+  const int W = (int)b->width, H = (int)b->height, PITCH = (int)b->pitch;
   HIP_TRY(hipMemsetAsync(b->d_fix_count + 2, 0, sizeof(uint32_t), st));
   if (lv->ntri)
     if (rdoom_status rs = launch_setup(st, n, lv->view, b->d_poses, object_modelviews ? (const ObjectConst *)b->d_objects : nullptr,
                                        lv->n_objects, W, H, kinds_mask, b->d_recs, b->d_visible, b->d_sorted, b->d_counts,
                                        b->d_ghist, b->cap, b->d_fix_count + 2))
       return rs;
+  HT_MARK(3);
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   bool split_lists = false;  // long tile lists stored per quadrant this render (binning kernel and rasteriser must agree)
   if (!(lv->ntri && !rdoom::debug_options().no_bins &&
@@ -478,20 +555,30 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     if (!lv->ntri) HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
   }
   if (marks) HIP_TRY(hipEventRecord(ev[1], st));
+  HT_MARK(4);
   uint32_t *prim_out = b->want_prim ? b->d_prim : nullptr;
   // one reading of the debug hooks for both kernels: who writes and who reads visibility words must not change in between
-  const FragmentPlan plan = plan_fragment(W, H, b->d_qtab != nullptr);
-  if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, W, H, tiles_x, tiles_y,
+  const FragmentPlan plan = plan_fragment(W, PITCH, H, b->d_qtab != nullptr);
+  // (the rasteriser's frame is PITCH pixels wide: the padding columns of a width that is not a multiple of 4 are pixels no
+  // bounding box reaches -- they stay uncovered, and the quadrants they lie in simply never count as covered)
+  if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, PITCH, H, tiles_x, tiles_y,
                                       b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out, b->d_qtab,
                                       plan.skip_described_vis, split_lists))
     return rs;
   if (marks) HIP_TRY(hipEventRecord(ev[2], st));
-  if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, b->d_poses, W, H, tiles_x,
+  HT_MARK(5);
+  if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, b->d_poses, W, PITCH, H, tiles_x,
                                         tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16,
                                         prim_out, b->d_ndc, b->d_fb, b->d_fix_count, b->d_fix_list, b->fix_cap, b->d_qtab, b->d_frag_const,
                                         &b->frag_const_ready, plan))
     return rs;
   HIP_TRY(hipGetLastError());
+  HT_MARK(6);
+  HIP_TRY(hipEventRecord(b->ev_done, st));
+  HT_MARK(7);
+#ifdef RDOOM_HOST_TIMERS
+  g_host_n++;
+#endif
   if (profiled) {
     HIP_TRY(hipEventRecord(ev[3], st));
     b->ring_n++;
@@ -506,7 +593,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     HIP_TRY(hipEventElapsedTime(&tm->total_ms, b->ev[0], b->ev[3]));
     tm->pixels = (uint64_t)n * W * H;
     std::vector<uint32_t> counts(n);
-    HIP_TRY(hipMemcpy(counts.data(), b->d_counts, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(read_back(b, counts.data(), b->d_counts, sizeof(uint32_t) * n));
     tm->visible_triangles = 0;
     for (uint32_t c : counts) tm->visible_triangles += c;
     uint32_t fixups = 0;
@@ -553,7 +640,7 @@ rdoom_status rdoom_batch_collect_timings(rdoom_batch *b, rdoom_timings *out, uin
   }
   out->pixels = (uint64_t)b->ring_poses * b->width * b->height;
   std::vector<uint32_t> counts(b->last_n);  // of the last render
-  HIP_TRY(hipMemcpy(counts.data(), b->d_counts, sizeof(uint32_t) * b->last_n, hipMemcpyDeviceToHost));
+  HIP_TRY(read_back(b, counts.data(), b->d_counts, sizeof(uint32_t) * b->last_n));
   for (uint32_t c : counts) out->visible_triangles += c;
   uint32_t fixups = 0;
   const rdoom_status fs = device_flags(b, &fixups);
@@ -579,8 +666,46 @@ rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out) {
 rdoom_status rdoom_batch_finish(rdoom_batch *b) {
   if (!b) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   HIP_TRY(bind_device(b));
-  HIP_TRY(hipDeviceSynchronize());
-  return device_flags(b);
+  return device_flags(b);  // (waits for the batch's last render on its own stream: read_back)
+}
+
+rdoom_status rdoom_batch_path_stats(rdoom_batch *b, rdoom_path_stats *out) {
+  if (!b || !out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out = rdoom_path_stats{};
+  HIP_TRY(bind_device(b));
+  if (rdoom_status fs = device_flags(b)) return fs;
+  const uint32_t n = b->last_n, T = b->n_tiles;
+  out->poses = n;
+  if (n == 0) return RDOOM_OK;
+  try {
+    std::vector<uint32_t> over(n), qtab((size_t)n * T * 4u);
+    std::vector<uint2> hdr((size_t)n * T);
+    HIP_TRY(read_back(b, over.data(), b->d_overflow, sizeof(uint32_t) * n));
+    HIP_TRY(read_back(b, hdr.data(), b->d_tile_hdr, sizeof(uint2) * hdr.size()));
+    HIP_TRY(read_back(b, qtab.data(), b->d_qtab, sizeof(uint32_t) * qtab.size()));
+    const uint32_t tiles_x = (b->width + TILE_W - 1) / TILE_W;
+    for (uint32_t p = 0; p < n; p++) {
+      const bool binned = over[p] == 0u;
+      out->bins_overflowed_poses += binned ? 0u : 1u;
+      for (uint32_t t = 0; t < T; t++) {
+        if (binned) {  // (the headers of a pose that overflowed are stale)
+          const uint2 h = hdr[(size_t)p * T + t];
+          out->split_tiles += (h.y & TILE_SPLIT) ? 1u : 0u;
+          out->tile_entries += h.y & ~TILE_SPLIT;
+        }
+        const uint32_t tx = (t % tiles_x) * TILE_W, ty = (t / tiles_x) * TILE_H;
+        for (uint32_t q = 0; q < 4u; q++) {
+          if (tx + (q & 1u) * 32u >= b->pitch || ty + (q >> 1) * 32u >= b->height) continue;  // outside the frame: never written
+          out->quadrants++;
+          out->described_quadrants += qtab[((size_t)p * T + t) * 4u + q] != NONE ? 1u : 0u;
+        }
+      }
+    }
+    out->tiles = (uint64_t)n * T;
+  } catch (const std::bad_alloc &) {
+    return rdoom::fail(RDOOM_OOM, "out of host memory");
+  }
+  return RDOOM_OK;
 }
 
 rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **out_device_ptr) {
@@ -589,14 +714,19 @@ rdoom_status rdoom_batch_framebuffer_device(const rdoom_batch *batch, uint8_t **
   return RDOOM_OK;
 }
 
+rdoom_status rdoom_batch_framebuffer_pitch(const rdoom_batch *batch, uint32_t *out_pitch) {
+  if (!batch || !out_pitch) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out_pitch = batch->pitch;
+  return RDOOM_OK;
+}
+
 rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *b, uint32_t first, uint32_t count, uint8_t *host_out) {
   if (!b || !host_out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   if ((uint64_t)first + count > b->last_n) return rdoom::fail(RDOOM_BAD_ARG, "frame range outside the last render");
-  const size_t frame = (size_t)b->width * b->height;
+  const size_t frame = (size_t)b->pitch * b->height;
   HIP_TRY(bind_device(b));
-  HIP_TRY(hipDeviceSynchronize());
   if (rdoom_status fs = device_flags(b)) return fs;
-  HIP_TRY(hipMemcpy(host_out, b->d_fb + frame * first, frame * count, hipMemcpyDeviceToHost));
+  if (count) HIP_TRY(read_back(b, host_out, b->d_fb + frame * first, b->width, (size_t)b->height * count, b->pitch));
   return RDOOM_OK;
 }
 
@@ -604,7 +734,7 @@ rdoom_status rdoom_batch_enable_primitive_ids(rdoom_batch *b) {
   if (!b) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   HIP_TRY(bind_device(b));  // the ids live next to the batch's other scratch, on the level's device
   if (!b->d_prim) {
-    const size_t npx = (size_t)b->width * b->height * b->max_poses;
+    const size_t npx = (size_t)b->pitch * b->height * b->max_poses;
     HIP_TRY(hipMalloc((void **)&b->d_prim, sizeof(uint32_t) * npx));
   }
   b->want_prim = true;
@@ -617,10 +747,10 @@ rdoom_status rdoom_batch_read_primitive_ids(rdoom_batch *b, uint32_t first, uint
   if (!b->want_prim || !b->d_prim)
     return rdoom::fail(RDOOM_BAD_ARG, "primitive ids are not captured: call rdoom_batch_enable_primitive_ids, then render");
   if ((uint64_t)first + count > b->last_n) return rdoom::fail(RDOOM_BAD_ARG, "frame range outside the last render");
-  const size_t frame = (size_t)b->width * b->height;
+  const size_t frame = (size_t)b->pitch * b->height;
   HIP_TRY(bind_device(b));
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(host_out, b->d_prim + frame * first, frame * count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (count)
+    HIP_TRY(read_back(b, host_out, b->d_prim + frame * first, sizeof(uint32_t) * b->width, (size_t)b->height * count, sizeof(uint32_t) * b->pitch));
   return RDOOM_OK;
 }
 

@@ -33,7 +33,8 @@ rdoom_status rdoom_debug_set(const char *name, int32_t value) {
                {"leak_mod", &o.leak_mod},   {"frag_nq", &o.frag_nq},       {"frag_bw", &o.frag_bw},
                {"frag_chunk", &o.frag_chunk}, {"bin_threads", &o.bin_threads}, {"no_cover", &o.no_cover},
                {"raster_stats", &o.raster_stats}, {"no_qtab", &o.no_qtab},
-               {"keep_vis", &o.keep_vis},   {"qpath", &o.qpath},           {"no_split", &o.no_split}};
+               {"keep_vis", &o.keep_vis},   {"qpath", &o.qpath},           {"no_split", &o.no_split},
+               {"no_pair", &o.no_pair}};
   for (const auto &t : table)
     if (std::strcmp(t.name, name) == 0) {
       *t.field = value;
@@ -128,7 +129,10 @@ rdoom_status rdoom_pose_from_player(const float pos[3], float yaw, float pitch, 
   const V3 disp{rc.x + pos[0], rc.y + pos[1], rc.z + pos[2]};
   // view = absolute.inverse_transform()
   const float s = 1.0f / scale;
-  const float mag2 = rot.s * rot.s + rot.x * rot.x + rot.y * rot.y + rot.z * rot.z;  // s * s + v.magnitude2(), as cgmath sums it
+  // Quaternion::magnitude2 = s * s + v.magnitude2(), and Vector3::magnitude2 = dot(v, v) sums its element products FIRST
+  // ((x x + y y) + z z) -- not s s + x x + y y + z z left to right, which differs in the last place for some rotations
+  const float vv = (rot.x * rot.x + rot.y * rot.y) + rot.z * rot.z;
+  const float mag2 = rot.s * rot.s + vv;
   const Quat r{rot.s / mag2, -rot.x / mag2, -rot.y / mag2, -rot.z / mag2};
   const V3 rd = rotate(r, disp);
   const V3 d{rd.x * -s, rd.y * -s, rd.z * -s};

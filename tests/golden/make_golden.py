@@ -49,11 +49,11 @@ def level_poses(lv, index):
         out[i, 16:32] = reference_projection(W, H)
         if i == 0:
             # the spawn view in the REFERENCE'S OWN ARITHMETIC (binary32 Decomposed / Quaternion, player.rs:124-131 +
-            # renderer.rs:78-87: rdoom_pose_from_player) -- BASELINE config 2's pose; it differs from the float64 helper above by
-            # a few units in the last place (tests/test_pose_helpers.py)
-            import rust_doom_amd as rd
-            p = rd.pose_from_player(sp, float(lv.start_yaw), 1e-8, W, H)
-            out[i, :16], out[i, 16:32] = p['modelview'], p['projection']
+            # renderer.rs:78-87) -- BASELINE config 2's pose; it differs from the float64 helper above by a few units in the last
+            # place.  From the oracle's own transcription (oracle/camera.py: numpy binary32 + glibc sinf / cosf / tanf), NOT from
+            # the library under test: tests/test_pose_helpers.py holds rdoom_pose_from_player to it bit for bit
+            from oracle import camera
+            out[i, :16], out[i, 16:32] = camera.pose_from_player(sp, float(lv.start_yaw), 1e-8, W, H)
         out[i, 32] = TIMES[i]
     return out
 

@@ -78,6 +78,26 @@ def test_rasteriser_without_the_quadrant_cover_body():
     assert bad == 0
 
 
+@pytest.mark.parametrize('hooks', [{'no_pair': 1}, {'no_pair': 1, 'no_split': 1}, {'no_pair': 1, 'keep_vis': 1}, {'no_pair': 1, 'no_bins': 1}])
+def test_rasteriser_without_the_two_entry_shortcut(hooks):
+    """no_pair=1: a quadrant shared by two triangles along a common edge (7 % of the passes at 1080p) is settled by the sign of
+    that edge function, without a depth compare -- a default-on exactness path that no_cover switched off only TOGETHER with the
+    one-entry shortcut.  With the hook it alone is off: the general pass must produce the same bytes."""
+    for args in (('0', '320', '200', '6'), ('0', '1920', '1080', '3'), ('4', '1280', '720', '3'), ('6', '1000', '520', '3')):
+        bad, _ = run_child(hooks, args)
+        assert bad == 0, (hooks, args)
+
+
+@pytest.mark.parametrize('size', [(322, 200), (1366, 768), (323, 131)])
+def test_padded_row_pitch_under_the_hooks(size):
+    """widths that are not a multiple of 4 (padded row pitch) through the paths that address pixels on their own: the alpha-leak
+    queue (leak_mod: fixup_kernel divides by the pitch), 32-bit visibility words, the sorted-list fallback, every block shape"""
+    for hooks in ({'leak_mod': 5}, {'vis32': 1, 'leak_mod': 11}, {'no_bins': 1}, {'frag_bw': 2}, {'frag_nq': 1}, {'frag_bw': 5}, {'no_qtab': 1},
+                  {'keep_vis': 1}, {'qpath': 1}):
+        bad, _ = run_child(hooks, ('0', str(size[0]), str(size[1]), '3'))
+        assert bad == 0, (hooks, size)
+
+
 @pytest.mark.parametrize('bw', [0, 2, 4, 6])
 def test_fragment_wave_block_shapes(bw):
     """1 x 64, 4 x 16, 16 x 4 and 64 x 1 units per wave (frame 320 x 200: 40 units per row, partial blocks in both

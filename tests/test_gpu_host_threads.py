@@ -66,6 +66,55 @@ def test_shared_level_four_threads_own_batches_and_streams(oracle_levels):
     assert not errors, errors
 
 
+def test_read_back_does_not_wait_for_another_threads_stream(oracle_levels):
+    """rdoom_batch_finish / rdoom_batch_read_* wait for THEIR batch's last render, on the stream it was queued on -- not for the
+    device (round-4 review, "boundary warts": they used to call hipDeviceSynchronize, so a thread-per-stream host stalled on other
+    threads' streams at every read-back).  Thread A queues two long renders (1080p x 1024 poses, several ms each) on its stream and
+    returns at once (rdoom_batch_render is asynchronous); the main thread then renders a small batch on another stream and reads it
+    back: when that read-back returns, A's stream must still be busy (hipStreamQuery == hipErrorNotReady) -- and the small frames
+    must be right."""
+    lv = oracle_levels(0)
+    level = rd.DeviceLevel(lv)
+    lights = lv.lights.fill_buffer_at(0.0)
+    hip = ctypes.CDLL('libamdhip64.so')
+    big_n, w, h, n = 1024, 256, 160, 3
+    big = rd.Batch(level, 1920, 1080, big_n)
+    big_poses = np.resize(sweep_poses(lv, 64, 1920, 1080, seed=5), big_n)
+    small = rd.Batch(level, w, h, n)
+    poses = sweep_poses(lv, n, w, h, seed=6)
+    ro = raster.RasterOracle(lv)
+    want = np.stack([ro.render(p['modelview'], p['projection'], 0.0, lights, w, h) for p in poses])
+    sa, sb = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(sa)) == 0 and hip.hipStreamCreate(ctypes.byref(sb)) == 0
+    big.render(big_poses, lights, stream=sa.value)   # warm-up: first-use allocations and the one-off constant upload happen here
+    small.render(poses, lights, stream=sb.value)
+    big.finish(), small.finish()
+    queued, errors = threading.Event(), []
+
+    def thread_a():
+        try:
+            rd.set_device(0)
+            big.render(big_poses, lights, stream=sa.value)
+            big.render(big_poses, lights, stream=sa.value)
+            queued.set()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+            queued.set()
+
+    th = threading.Thread(target=thread_a)
+    th.start()
+    assert queued.wait(120) and not errors, errors
+    small.render(poses, lights, stream=sb.value)
+    fb = small.read_framebuffer()
+    busy = hip.hipStreamQuery(sa)                    # 600 = hipErrorNotReady: A's renders are still running
+    th.join(120)
+    big.finish()
+    assert np.array_equal(fb, want)
+    assert busy == 600, 'the small read-back returned only after the other thread\'s stream had drained (hipStreamQuery = %d)' % busy
+    big.close(), small.close()
+    assert hip.hipStreamDestroy(sa) == 0 and hip.hipStreamDestroy(sb) == 0
+
+
 def test_last_error_is_thread_local(oracle_levels):
     lib = rd.lib()
     lib.rdoom_last_error.restype = ctypes.c_char_p

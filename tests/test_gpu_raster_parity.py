@@ -75,6 +75,28 @@ def test_kat_level_and_odd_sizes(oracle_levels):
     run_case(lv, 1920, 1080, 2, rd.ALL_KINDS)  # BASELINE resolution
 
 
+def test_any_window_size(oracle_levels):
+    """The reference takes any --resolution WxH (src/main.rs:41): widths that are not a multiple of 4 render with a padded row
+    pitch (rdoom.h: rdoom_batch_framebuffer_pitch) and read back tightly packed; heights that are not a multiple of 4 have pixel
+    rows below the frame in their bottom block row (raster.hip: they start at depth 0).  1366x768 and 1600x900 are the sizes the
+    round-4 review names; 322 / 321 / 323 pad by 6 / 7 / 5 columns (a whole 4-pixel block of padding in the first two)."""
+    lv = oracle_levels(1)
+    for w, h, n in ((322, 200, 4), (321, 199, 3), (323, 130, 3), (1366, 768, 2), (1600, 900, 2), (1921, 1082, 1), (5, 3, 2), (9, 70, 2)):
+        run_case(lv, w, h, n, rd.ALL_KINDS)
+    lv = oracle_levels(0)
+    run_case(lv, 1366, 768, 3, rd.ALL_KINDS, time=0.9)
+    run_case(lv, 1920, 1082, 2, rd.ALL_KINDS)   # height % 4 == 2: the bottom quadrant row crosses the frame's edge inside a block
+
+
+def test_framebuffer_pitch(oracle_levels):
+    lv = oracle_levels(1)
+    dev = rd.DeviceLevel(lv)
+    for w, want in ((320, 320), (324, 324), (322, 328), (321, 328), (1366, 1368), (4, 8), (1, 8)):
+        b = rd.Batch(dev, w, 16, 1)
+        assert b.framebuffer_pitch() == want, (w, b.framebuffer_pitch())
+        b.close()
+
+
 def test_4k_time_varying(oracle_levels):
     """BASELINE config 5's frame size (3840x2160) with animated flats, scrolling walls and the per-pose light
     table at t != 0, on the synthetic E1M3 (no DOOM2.WAD exists here): 2040 tiles per frame, 8.3 Mpixel."""
@@ -187,7 +209,15 @@ def test_edge_cases(oracle_levels):
     with pytest.raises(rd.RdoomError):
         b.render(np.zeros(3, rd.POSE), lights)                  # more poses than max_poses
     with pytest.raises(rd.RdoomError):
-        rd.Batch(dev, 66, 40, 1)                                # width must be a multiple of 4
+        rd.Batch(dev, 0, 40, 1)                                 # an empty frame
+    with pytest.raises(rd.RdoomError):
+        rd.Batch(dev, 16388, 40, 1)                             # beyond 16384 on a side
+    odd = rd.Batch(dev, 66, 40, 1)                              # any width (round 4: "width must be a multiple of 4")
+    p66 = np.zeros(1, rd.POSE)
+    p66['modelview'] = np.eye(4, dtype=np.float32).reshape(16)
+    p66['projection'] = reference_projection(66, 40)
+    odd.render(p66, lights)
+    assert np.array_equal(odd.read_framebuffer()[0], raster.RasterOracle(lvl).render(p66[0]['modelview'], p66[0]['projection'], 0.0, lights, 66, 40))
     small = rd.Batch(dev, 8, 1, 1)                              # one row of eight pixels
     p = np.zeros(1, rd.POSE)
     p['modelview'] = np.eye(4, dtype=np.float32).reshape(16)

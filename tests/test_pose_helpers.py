@@ -55,6 +55,36 @@ def test_spawn_pose_of_e1m1_two_helpers_agree_to_a_few_ulps():
     assert np.array_equal(golden[0, 0, :16], a['modelview']) and np.array_equal(golden[0, 0, 16:32], a['projection'])
 
 
+def test_from_player_equals_the_binary32_transcription_bit_for_bit():
+    """oracle/camera.py restates the cgmath chain one numpy float32 operation at a time (sinf / cosf / tanf from glibc, as Rust's
+    f32::sin lowers to); the C helper must produce the SAME BITS -- including Quaternion::magnitude2's summation order
+    (s s + ((x x + y y) + z z)), which round 4's helper had as a left-to-right sum.  The golden poses are
+    generated from the transcription, so this also ties rdoom_pose_from_player to tests/golden/poses.npy."""
+    from oracle import camera
+    rng = np.random.RandomState(20260922)
+    order_matters = 0
+    for k in range(6000):
+        pos = rng.uniform(-60, 60, 3).astype(np.float32)
+        yaw = np.float32(rng.uniform(-7, 7))
+        pitch = np.float32(1e-8) if k % 3 == 0 else np.float32(rng.uniform(-1.5, 1.5))
+        w, h = ((320, 200), (1920, 1080), (1366, 768))[k % 3]
+        a = rd.pose_from_player(pos, yaw, pitch, w, h)
+        mv, pr = camera.pose_from_player(pos, yaw, pitch, w, h)
+        assert np.array_equal(a['modelview'].view(np.uint32), mv.view(np.uint32)), (k, pos, yaw, pitch)
+        assert np.array_equal(a['projection'].view(np.uint32), pr.view(np.uint32)), (k, w, h)
+        # how often the summation order decides a bit (so that the test above really discriminates)
+        sx, cx, sy, cy = camera.sinf(pitch * np.float32(0.5)), camera.cosf(pitch * np.float32(0.5)), camera.sinf(yaw * np.float32(0.5)), camera.cosf(yaw * np.float32(0.5))
+        q = (cx * cy, sx * cy, sy * cx, sx * sy)
+        order_matters += int((q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]) != (q[0] * q[0] + ((q[1] * q[1] + q[2] * q[2]) + q[3] * q[3])))
+    assert order_matters > 50, order_matters
+    golden = np.load(GOLDEN + '/poses.npy')
+    wad = rd.Wad(ensure_wad(), META_PATH)
+    for index in range(golden.shape[0]):
+        pos, yaw = wad.build_level(index).start()
+        mv, pr = camera.pose_from_player(pos, yaw, 1e-8, 320, 200)
+        assert np.array_equal(golden[index, 0, :16], mv) and np.array_equal(golden[index, 0, 16:32], pr), index
+
+
 def test_reset_poses_against_the_float64_composition():
     worst = 0.0
     for k in range(16):

@@ -99,3 +99,32 @@ def test_bench_gpus_flag_spawns_the_ranks():
         for lo, hi, digest in line['pose_ranges']:
             full = sharding.pose_sweep(rd, built, hi - lo, 64, 40, first=lo)
             assert hashlib.sha256(full.tobytes()).hexdigest()[:16] == digest
+
+
+def test_bench_threads_launcher_partitions_like_the_process_launcher():
+    """`--launcher threads`: one process, one host thread per GPU through the C ABI only (the shape INTEGRATION.md gives a Rust
+    host).  Its dry run must hand every thread the pose range -- and the very poses -- the process launcher hands its ranks."""
+    import json
+    import subprocess
+    import sys
+    from util import ROOT
+    lines = {}
+    for launcher in ('processes', 'threads'):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--poses', '24', '--width', '64',
+                              '--height', '40', '--scaling', 'strong', '--launcher', launcher], capture_output=True, text=True, timeout=600,
+                             env={k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')})
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines[launcher] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert lines['threads']['launcher'] == 'threads' and lines['threads']['n_gpus'] == 2
+    assert lines['threads']['pose_ranges'] == lines['processes']['pose_ranges'] == [[0, 12, lines['threads']['pose_ranges'][0][2]],
+                                                                                    [12, 24, lines['threads']['pose_ranges'][1][2]]]
+
+
+def test_stream_plans():
+    """one level: its poses as S sub-batches; several levels alternate over the stream pool as one batch each"""
+    import sys
+    from util import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.resolve_streams(0, 1) == 2 and bench.resolve_streams(0, 9) == 3 and bench.resolve_streams(4, 9) == 4
+    assert bench.parts_per_level(1, 2) == 2 and bench.parts_per_level(9, 3) == 1 and bench.parts_per_level(2, 4) == 2 and bench.parts_per_level(1, 1) == 1
