@@ -239,8 +239,8 @@ rdoom_status rdoom_selftest_fastmath(uint64_t out_counts[8]);
  * shaped but EQUIVALENT path through the kernels -- the image must not change -- so that the rarely taken ones can be
  * forced (tests/test_gpu_debug_paths.py).  Process-wide; read when a batch is created ("vis32", "entry_cap") or
  * rendered (the rest).  Names: no_bins, entry_cap, vis32, leak_mod, frag_nq, frag_bw, frag_chunk, bin_threads,
- * no_cover, no_pair, raster_stats, no_qtab, keep_vis, qpath, no_split (rust-doom_amd/csrc/common.hpp: DebugOptions); "reset" restores the
- * defaults. */
+ * no_cover, no_pair, no_settle, settle_max, raster_stats, no_qtab, keep_vis, qpath, no_split (rust-doom_amd/csrc/common.hpp:
+ * DebugOptions); "reset" restores the defaults. */
 rdoom_status rdoom_debug_set(const char *name, int32_t value);
 
 /* ---- loader + builder: the `wad` crate and `game::level` static-geometry builder ----------- */

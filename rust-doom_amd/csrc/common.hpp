@@ -25,6 +25,8 @@ struct DebugOptions {
   int qpath = 0;         // the whole-quadrant fragment kernel runs first (off by default: measured slower)
   int keep_vis = 0;      // the rasteriser writes the visibility words of every quadrant, also of those the table describes
   int no_pair = 0;       // no two-entry shortcut in the rasteriser (a quadrant shared by two triangles along a common edge takes the general pass)
+  int no_settle = 0;     // no settle_kernel: the rasteriser's waves find the one-triangle quadrants themselves, as before round 5
+  int settle_max = 0;    // longest tile list settle_kernel examines (0 = default, raster.hip RDOOM_SETTLE_MAX)
   int no_split = 0;      // no per-quadrant lists for tiles with more than 64 entries: the rasteriser re-gathers such a tile's whole list for every quadrant
   int raster_stats = 0;  // census of the rasteriser's paths on stderr (instrumented instantiation: slower)
 };

@@ -40,7 +40,8 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
                            const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out,
                            uint32_t *qtab,  // qtab (optional): per (pose, tile, quadrant) the record all its pixels show, or NONE
                            bool skip_described_vis,  // no visibility words for quadrants the table describes (FragmentPlan)
-                           bool split_lists);  // the binning kernel stored long lists per quadrant (launch_bin's answer for this render)
+                           bool split_lists,  // the binning kernel stored long lists per quadrant (launch_bin's answer for this render)
+                           bool bins_launched);  // the binning kernel ran (its overflow flags are this render's): settle_kernel may read the lists
 // How the fragment kernel will walk a frame of this size, decided ONCE per render from the debug hooks (rasteriser and
 // fragment kernel must agree on who reads the quadrant table): quads per lane, log2(units per block row), blocks per
 // workgroup wave, the test hook leak_mod, and qtab_mode (0: table unused; 1 / 2: a wave block lies in one / two quadrants).

@@ -264,9 +264,104 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {  // (the same red
   return min(min(a, b), min(c, d));
 }
 
+// =================================================================================================
+// Kernel 2a: settle.  Seven quadrants in ten of a 1080p sweep show ONE triangle: the nearest entry of the tile's list covers the
+// quadrant entirely and every other entry lies strictly behind its farthest depth there -- the rasteriser's one-entry shortcut.
+// The rasteriser finds that out with a WAVE per tile: header, entries and 80-byte records by three dependent memory round
+// trips, the per-quadrant corner arithmetic of every entry with 7 of 64 lanes busy, wave-wide minima and ballots -- and then
+// stores four bytes.  Here a LANE per (tile, quadrant) walks the tile's list itself (lists of at most `max_list` entries,
+// stored whole): of each entry that touches its quadrant (the binning kernel's bits) it needs only the depth plane -- the
+// nearest depth over the quadrant, a corner value --, keeps the nearest and the second nearest, and evaluates the cover test
+// and the farthest depth once, for the nearest entry.  Same corner arguments, same strictness, hence the same decisions as the
+// shortcut (a depth tie between the two nearest leaves the quadrant to the rasteriser, as there).  A settled quadrant gets its
+// table entry HERE; every other quadrant inside the frame gets QTAB_TODO, and the rasteriser's wave for the tile starts by
+// reading the tile's four entries: nothing to do -> it ends after one scalar load; else it passes only the TODO quadrants.
+// (Instantiations that store visibility words or primitive ids for described quadrants -- tests -- ignore this and do everything.)
+// Poses whose bins overflowed are left alone: the rasteriser scans their sorted lists as before.
+// =================================================================================================
+constexpr uint32_t QTAB_TODO = 0xFFFFFFFEu;  // (not NONE, not a record index: the rasteriser replaces every one before anybody else reads the table)
+__global__ __launch_bounds__(256) void settle_kernel(const TriRec *__restrict__ recs, uint32_t cap, uint32_t n_poses, int width, int height,
+                                                     int tiles_x, int tiles_y, const uint2 *__restrict__ tile_hdr,
+                                                     const uint32_t *__restrict__ entries, uint32_t entry_cap,
+                                                     const uint32_t *__restrict__ overflow, uint32_t *__restrict__ qtab, uint32_t max_list) {
+  const uint32_t T = (uint32_t)(tiles_x * tiles_y);
+  const uint32_t pose = blockIdx.z * 8u + (blockIdx.x & 7u);  // a pose's tiles on one XCD, like the rasteriser's
+  const uint32_t idx = (blockIdx.x >> 3) * 256u + threadIdx.x, tile = idx >> 2, q = idx & 3u;
+  if (pose >= n_poses || tile >= T) return;
+  if (overflow[pose] != 0u) return;
+  const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE_W, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE_H;
+  const int rx0 = tx0 + (int)(q & 1u) * 32, ry0 = ty0 + (int)(q >> 1) * 32;
+  if (rx0 >= width || ry0 >= height) return;  // outside the frame: NONE from the start, never written
+  const TriRec *prec = recs + (size_t)pose * cap;
+  const uint2 hdr = tile_hdr[(size_t)pose * T + tile];
+  uint32_t out = QTAB_TODO;
+  if ((hdr.y & TILE_SPLIT) == 0u && hdr.y != 0u && hdr.y <= max_list) {
+    const uint32_t *pent = entries + (size_t)pose * entry_cap + hdr.x;
+    const float xl = (float)rx0 + 0.5f, xh = (float)rx0 + 31.5f, yl = (float)ry0 + 0.5f, yh = (float)ry0 + 31.5f;
+    uint32_t m1 = NONE, m2 = NONE, best = NONE;
+    // four entries at a time: their words first, then the depth planes of those that touch my quadrant -- the loads of a group
+    // are in flight together (a lane that walked its list one entry at a time spent its life in two dependent round trips per entry)
+    for (uint32_t i = 0; i < hdr.y; i += 4u) {
+      uint32_t e[4];
+      uint4 c2[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++) e[k] = i + k < hdr.y ? pent[i + k] : 0u;  // (0: touches nothing)
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++)
+        if ((e[k] >> (28u + q)) & 1u) c2[k] = reinterpret_cast<const uint4 *>(&prec[e[k] & ENTRY_REC_MASK])[2];
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++) {
+        if (((e[k] >> (28u + q)) & 1u) == 0u) continue;  // does not touch my quadrant (exact tests of the binning kernel)
+        const float za = __uint_as_float(c2[k].y), zb = __uint_as_float(c2[k].z), zc = __uint_as_float(c2[k].w);
+        const float zn = fmaf(za, pos(za) ? xl : xh, fmaf(zb, pos(zb) ? yl : yh, zc));
+        const uint32_t dn = zn <= 1.0f ? __float2uint_rz(fmaf(fminf(fmaxf(zn, 0.0f), 1.0f), 16777215.0f, 0.5f)) : NONE;
+        if (dn < m1) {
+          m2 = m1, m1 = dn, best = e[k] & ENTRY_REC_MASK;
+        } else {
+          m2 = min(m2, dn);  // (dn == m1: a tie of the two nearest -- m2 = m1 cannot be strictly behind anything)
+        }
+      }
+    }
+    if (best != NONE) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[best]);
+      const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3];
+      const uint2 c4 = *reinterpret_cast<const uint2 *>(rp + 4);
+      const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
+                  e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
+                  e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x);
+      const float za = __uint_as_float(c2.y), zb = __uint_as_float(c2.z), zc = __uint_as_float(c2.w);
+      const float wa = __uint_as_float(c3.x), wb = __uint_as_float(c3.y), wc = __uint_as_float(c3.z);
+      const int x0 = (int)(c3.w & 0xFFFFu), y0 = (int)(c3.w >> 16), x1 = (int)(c4.x & 0xFFFFu), y1 = (int)(c4.x >> 16);
+      // the cover test of the rasteriser's gather, for this one entry and quadrant: smallest corner values of the edge
+      // functions and of 1/w, the depth range over the quadrant, the bbox (clipped to the frame), an opaque texture rectangle
+      const float zn = fmaf(za, pos(za) ? xl : xh, fmaf(zb, pos(zb) ? yl : yh, zc));
+      const float zf = fmaf(za, pos(za) ? xh : xl, fmaf(zb, pos(zb) ? yh : yl, zc));
+      const float n0 = fmaf(e0a, pos(e0a) ? xl : xh, fmaf(e0b, pos(e0b) ? yl : yh, e0c));
+      const float n1 = fmaf(e1a, pos(e1a) ? xl : xh, fmaf(e1b, pos(e1b) ? yl : yh, e1c));
+      const float n2 = fmaf(e2a, pos(e2a) ? xl : xh, fmaf(e2b, pos(e2b) ? yl : yh, e2c));
+      const float rwn = fmaf(wa, pos(wa) ? xl : xh, fmaf(wb, pos(wb) ? yl : yh, wc));
+#ifndef RDOOM_NO_EDGE_COVER
+      const int qx1 = min(rx0 + 31, width - 1), qy1 = min(ry0 + 31, height - 1);
+#else
+      const int qx1 = rx0 + 31, qy1 = ry0 + 31;
+#endif
+      const bool cover = (zn >= 0.0f) & (zf <= 1.0f) & (rwn > 0.0f) & (x0 <= rx0) & (x1 >= qx1) & (y0 <= ry0) & (y1 >= qy1) &
+                         ((c4.y & RASTER_MASKED_INTERIOR) == 0u) & (n0 > 0.0f) & (n1 > 0.0f) & (n2 > 0.0f);
+      if (cover) {
+        const uint32_t df0 = __float2uint_rz(fmaf(zf, 16777215.0f, 0.5f));  // zf in [0, 1]: the entry covers
+        if (m2 > df0) out = best;  // everything else strictly behind its farthest depth: it wins all 1024 pixels
+      }
+    }
+  }
+  qtab[((size_t)pose * T + tile) * 4u + q] = out;
+}
+
 #ifndef RDOOM_RANK_LIMIT
 #define RDOOM_RANK_LIMIT 0  // a batch of a binned list with more entries than this is walked in list order, unranked (0: always --
                             // ranking every batch by record index measured 1 % slower at 1080p and 8 % slower on the large level)
+#endif
+#ifndef RDOOM_SETTLE_MAX
+#define RDOOM_SETTLE_MAX 32  // settle_kernel examines whole lists of at most this many entries (a lane walks the list: longer ones are the rasteriser's)
 #endif
 #ifndef RDOOM_RASTER_OCC
 #define RDOOM_RASTER_OCC 4  // waves per SIMD the register allocation aims at (128 VGPRs)
@@ -294,7 +389,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
                                                              const uint32_t *__restrict__ overflow,
                                                              uint32_t *__restrict__ vis,
                                                              uint32_t *__restrict__ prim_out, uint32_t no_cover,
-                                                             uint32_t *__restrict__ qtab,
+                                                             uint32_t *__restrict__ qtab, uint32_t settled,
                                                              unsigned long long *__restrict__ stats) {
   unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __shared__ uint32_t wq[RASTER_WAVES][64];
@@ -319,6 +414,14 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   const uint32_t over = overflow[pose], all_visible = counts[pose];
   const uint2 hdr_binned = tile_hdr[(size_t)pose * T + tile];
   const bool binned = over == 0u;  // the pose's per-tile lists are complete
+  // settle_kernel ran over this pose's lists (settled != 0, bins complete): the tile's four table entries say which quadrants are
+  // still to do.  Instantiations that owe visibility words or primitive ids to EVERY quadrant do them all, as before.
+  uint32_t todo = 0xFu;
+  if (SKIPVIS && !PRIM && settled != 0u && binned) {
+    const uint4 qt = *reinterpret_cast<const uint4 *>(qtab + ((size_t)pose * T + tile) * 4u);  // (uniform address: a scalar load)
+    todo = (qt.x == QTAB_TODO ? 1u : 0u) | (qt.y == QTAB_TODO ? 2u : 0u) | (qt.z == QTAB_TODO ? 4u : 0u) | (qt.w == QTAB_TODO ? 8u : 0u);
+    if (todo == 0u) return;
+  }
   // A tile with a long list (more than 64 entries: far geometry, small triangles that touch one quadrant each) comes with a list
   // PER QUADRANT (bin.hip, "split lists"): each quadrant's pass starts with the gather of ITS list -- most of those fit one
   // batch again (one gather, the shortcuts apply), and a quadrant's pass no longer gathers the records of the other three.
@@ -456,7 +559,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   // behind that entry's farthest depth over the whole tile.
   // (Whole tiles only: its stores carry no frame checks.  The quadrants of a tile that crosses the frame's edge take the
   // quadrant-level shortcut below.)
-  if (!split && single && n != 0u && tx0 + TILE_W <= width && ty0 + TILE_H <= height) {
+  if (!split && single && n != 0u && todo == 0xFu && tx0 + TILE_W <= width && ty0 + TILE_H <= height) {
     // my entry's nearest depth over the quadrants it touches (lanes without an entry hold NONE everywhere)
     const uint32_t tq = myrq >> 24;
     const uint32_t near_all = min(min((tq & 1u) ? dnq0 : NONE, (tq & 2u) ? dnq1 : NONE), min((tq & 4u) ? dnq2 : NONE, (tq & 8u) ? dnq3 : NONE));
@@ -510,6 +613,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   for (int q = 0; q < 4; q++) {
     const int qx0 = tx0 + (q & 1) * 32, qy0 = ty0 + (q >> 1) * 32;  // this quadrant
     if (qx0 >= width || qy0 >= height) continue;                    // entirely outside the frame (partial tiles)
+    if (((todo >> q) & 1u) == 0u) continue;                         // settled by settle_kernel: its table entry stands
     const int bx = qx0 + lx, by = qy0 + ly;                         // this lane's 4x4 block
     const float pxlo = (float)bx + 0.5f, pxhi = (float)bx + 3.5f, pylo = (float)by + 0.5f, pyhi = (float)by + 3.5f;
     if (split) {  // this quadrant's own list: (first entry, count) from the tile's sub-header
@@ -855,7 +959,7 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
                            const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out, uint32_t *qtab,
-                           bool skip_described_vis, bool split_lists) {
+                           bool skip_described_vis, bool split_lists, bool bins_launched) {
   const uint32_t n = n_poses;
   const uint32_t groups = (n + 7u) / 8u;  // pose groups of eight: one pose per XCD
   if (groups > 65535u || tiles_y > 65535 || (uint64_t)tiles_x * 8ull > 0x7FFFFFFFull)
@@ -877,9 +981,18 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
                             : (skip ? pick(std::false_type{}, std::true_type{}, splt) : pick(std::false_type{}, std::false_type{}, splt));
   };
   auto rk = split_lists ? pick2(std::true_type{}) : pick2(std::false_type{});
+  // settle_kernel first (see there): only where the rasteriser may skip what it settles -- the table is in use, no visibility
+  // words or primitive ids are owed for described quadrants, the one-entry shortcut is not switched off by a hook
+  const uint32_t max_list = dbg.settle_max > 0 ? (uint32_t)dbg.settle_max : RDOOM_SETTLE_MAX;
+  const bool settle = skip && !prim_out && !dbg.no_settle && !dbg.no_cover && !dbg.raster_stats && bins_launched;
+  if (settle) {
+    const uint32_t T4 = (uint32_t)(tiles_x * tiles_y) * 4u;
+    hipLaunchKernelGGL(settle_kernel, dim3(((T4 + 255u) / 256u) * 8u, 1, groups), dim3(256), 0, st, recs, cap, n, width, height, tiles_x, tiles_y, tile_hdr,
+                       entries, entry_cap, overflow, qtab, max_list);
+  }
   hipLaunchKernelGGL(rk, dim3((uint32_t)tiles_x * 8u, (uint32_t)tiles_y, groups), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, (dbg.no_cover ? 1u : 0u) | (dbg.no_pair ? 2u : 0u),
-                     qtab, d_stats);
+                     qtab, settle ? 1u : 0u, d_stats);
 #ifdef RDOOM_CENSUS_TWO
   {
     unsigned long long h[64], zero[64] = {};

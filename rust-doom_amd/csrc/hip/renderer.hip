@@ -548,9 +548,10 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   HT_MARK(3);
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   bool split_lists = false;  // long tile lists stored per quadrant this render (binning kernel and rasteriser must agree)
-  if (!(lv->ntri && !rdoom::debug_options().no_bins &&
-        launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
-                   b->entry_cap, b->d_hits, b->d_overflow, !rdoom::debug_options().no_split, &split_lists))) {
+  const bool bins = lv->ntri && !rdoom::debug_options().no_bins &&
+                    launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
+                               b->entry_cap, b->d_hits, b->d_overflow, !rdoom::debug_options().no_split, &split_lists);
+  if (!bins) {
     HIP_TRY(hipMemsetAsync(b->d_overflow, 0xFF, sizeof(uint32_t) * n, st));
     if (!lv->ntri) HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
   }
@@ -563,7 +564,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   // bounding box reaches -- they stay uncovered, and the quadrants they lie in simply never count as covered)
   if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, PITCH, H, tiles_x, tiles_y,
                                       b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out, b->d_qtab,
-                                      plan.skip_described_vis, split_lists))
+                                      plan.skip_described_vis, split_lists, bins))
     return rs;
   if (marks) HIP_TRY(hipEventRecord(ev[2], st));
   HT_MARK(5);

@@ -34,7 +34,7 @@ rdoom_status rdoom_debug_set(const char *name, int32_t value) {
                {"frag_chunk", &o.frag_chunk}, {"bin_threads", &o.bin_threads}, {"no_cover", &o.no_cover},
                {"raster_stats", &o.raster_stats}, {"no_qtab", &o.no_qtab},
                {"keep_vis", &o.keep_vis},   {"qpath", &o.qpath},           {"no_split", &o.no_split},
-               {"no_pair", &o.no_pair}};
+               {"no_pair", &o.no_pair},     {"no_settle", &o.no_settle},   {"settle_max", &o.settle_max}};
   for (const auto &t : table)
     if (std::strcmp(t.name, name) == 0) {
       *t.field = value;
