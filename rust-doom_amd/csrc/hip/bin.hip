@@ -153,34 +153,58 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
       const uint32_t W = scan_tmp[BIN_THREADS / 64 - 1];
       if (tid == 0) pref[BIN_CHUNK] = W;
       __syncthreads();
-      for (uint32_t w = (uint32_t)tid; w < W; w += BIN_THREADS) {
-        // largest i with pref[i] <= w (pref non-decreasing, pref[0] = 0, pref[BIN_CHUNK] = W > w); triangles
-        // past cn have pref == W and are never selected
-        uint32_t lo = 0, hi = BIN_CHUNK;
+      // Two pairs per thread and iteration, stage by stage (both binary searches, then both pairs' coefficient reads and tests,
+      // then the counters): the workgroup is alone with its latencies -- eight dependent LDS reads of the search, three 16-byte
+      // reads, the atomics -- and a second independent pair fills them.  The hit index comes from ONE atomic per wave (ballot +
+      // prefix count): a per-pair returning atomic on one LDS word serialised the 64 lanes.
+      constexpr uint32_t PAIRS = 2;
+      for (uint32_t w0 = (uint32_t)tid; w0 < W; w0 += PAIRS * BIN_THREADS) {
+        uint32_t wq[PAIRS], lo[PAIRS], hi[PAIRS];
+#pragma unroll
+        for (uint32_t u = 0; u < PAIRS; u++) wq[u] = w0 + u * BIN_THREADS, lo[u] = 0u, hi[u] = BIN_CHUNK;
+        // largest i with pref[i] <= w (pref non-decreasing, pref[0] = 0, pref[BIN_CHUNK] = W > w); triangles past cn have
+        // pref == W and are never selected (a w past W selects nothing: masked below)
 #pragma unroll
         for (int step = 0; step < BIN_LOG2; step++) {
-          const uint32_t mid = (lo + hi) >> 1;
-          const bool le = pref[mid] <= w;
-          lo = le ? mid : lo;
-          hi = le ? hi : mid;
+#pragma unroll
+          for (uint32_t u = 0; u < PAIRS; u++) {
+            const uint32_t mid = (lo[u] + hi[u]) >> 1;
+            const bool le = pref[mid] <= wq[u];
+            lo[u] = le ? mid : lo[u];
+            hi[u] = le ? hi[u] : mid;
+          }
         }
-        const uint32_t t = w - pref[lo];
-        const uint2 bb = bbox[lo];
-        const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
-        const uint32_t tr = trange[lo];
-        const int tx0 = (int)(tr & 0xFFu), ty0 = (int)((tr >> 8) & 0xFFu), ntx = (int)(tr >> 16);
-        const int ty = (int)(((float)t + 0.5f) / (float)ntx), tx = (int)t - ty * ntx;  // t / ntx (t < 8192: exact)
-        const uint4 c0 = coef[lo][0], c1 = coef[lo][1], c2 = coef[lo][2];
-        uint32_t qm = 0;
-        if (tile_may_touch(c0, c1, c2, (tx0 + tx) * 64, (ty0 + ty) * 64))
-          qm = tile_quadrant_mask(c0, c1, c2, x0, y0, x1, y1, (tx0 + tx) * 64, (ty0 + ty) * 64);
-        if (qm) {
-          const uint32_t tile = (uint32_t)((ty0 + ty) * tiles_x + tx0 + tx);
-          atomicAdd(&tile_cnt[tile], 1u);
-          if (split)
-            atomicAdd(&qc[tile], (unsigned long long)((qm & 1u) | ((qm & 2u) << 15)) | ((unsigned long long)(((qm >> 2) & 1u) | ((qm & 8u) << 13)) << 32));
-          const uint32_t k = atomicAdd(&n_hits, 1u);  // (a pose with more than entry_cap pairs overflows below)
-          if (k < entry_cap) phits[k] = make_uint2((cbase + lo) | (qm << 28), tile);
+        uint32_t qm[PAIRS], tile[PAIRS];
+#pragma unroll
+        for (uint32_t u = 0; u < PAIRS; u++) {
+          qm[u] = 0u, tile[u] = 0u;
+          if (wq[u] < W) {
+            const uint32_t t = wq[u] - pref[lo[u]];
+            const uint2 bb = bbox[lo[u]];
+            const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
+            const uint32_t tr = trange[lo[u]];
+            const int tx0 = (int)(tr & 0xFFu), ty0 = (int)((tr >> 8) & 0xFFu), ntx = (int)(tr >> 16);
+            const int ty = (int)(((float)t + 0.5f) / (float)ntx), tx = (int)t - ty * ntx;  // t / ntx (t < 8192: exact)
+            const uint4 c0 = coef[lo[u]][0], c1 = coef[lo[u]][1], c2 = coef[lo[u]][2];
+            if (tile_may_touch(c0, c1, c2, (tx0 + tx) * 64, (ty0 + ty) * 64))
+              qm[u] = tile_quadrant_mask(c0, c1, c2, x0, y0, x1, y1, (tx0 + tx) * 64, (ty0 + ty) * 64);
+            tile[u] = (uint32_t)((ty0 + ty) * tiles_x + tx0 + tx);
+          }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < PAIRS; u++) {
+          const unsigned long long hitm = __ballot(qm[u] != 0u);
+          if (hitm == 0ull) continue;  // (wave-uniform)
+          uint32_t first = 0;
+          if ((threadIdx.x & 63u) == 0u) first = atomicAdd(&n_hits, (uint32_t)__popcll(hitm));  // (a pose with more than entry_cap pairs overflows below)
+          first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+          if (qm[u]) {
+            atomicAdd(&tile_cnt[tile[u]], 1u);
+            if (split)
+              atomicAdd(&qc[tile[u]], (unsigned long long)((qm[u] & 1u) | ((qm[u] & 2u) << 15)) | ((unsigned long long)(((qm[u] >> 2) & 1u) | ((qm[u] & 8u) << 13)) << 32));
+            const uint32_t k = first + (uint32_t)__popcll(hitm & ((1ull << (threadIdx.x & 63u)) - 1ull));
+            if (k < entry_cap) phits[k] = make_uint2((cbase + lo[u]) | (qm[u] << 28), tile[u]);
+          }
         }
       }
     }
@@ -238,22 +262,31 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
     }
     __syncthreads();  // cursors, and the split tiles' sub-headers (global memory written by this workgroup), are in place
     // fill: the pairs are read back in the order they were found (near to far up to a window of BIN_CHUNK triangles)
+    // (four pairs per thread and iteration, their loads and cursor atomics in flight together: the pass is a chain of
+    // load -> LDS atomic -> store per pair, and a workgroup has nothing else to hide it behind)
     const uint32_t found = n_hits;
-    for (uint32_t k0 = 0; k0 < found; k0 += BIN_THREADS) {
-      const uint32_t k = k0 + (uint32_t)tid;
-      if (k < found) {
-        const uint2 h = phits[k];
-        const uint32_t cur = tile_cnt[h.y];
+    constexpr uint32_t FILL_UNROLL = 4;
+    for (uint32_t k0 = 0; k0 < found; k0 += FILL_UNROLL * BIN_THREADS) {
+      uint2 h[FILL_UNROLL];
+#pragma unroll
+      for (uint32_t u = 0; u < FILL_UNROLL; u++) {
+        const uint32_t k = k0 + u * BIN_THREADS + (uint32_t)tid;
+        h[u] = k < found ? phits[k] : make_uint2(0u, NONE);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < FILL_UNROLL; u++) {
+        if (h[u].y == NONE) continue;
+        const uint32_t cur = tile_cnt[h[u].y];
         if (!(cur & TILE_SPLIT)) {
-          pent[atomicAdd(&tile_cnt[h.y], 1u)] = h.x;
+          pent[atomicAdd(&tile_cnt[h[u].y], 1u)] = h[u].x;
         } else {
           // one copy per quadrant touched: ONE atomic advances the cursors of all of them and returns where each copy goes
-          const uint32_t base = cur & ~TILE_SPLIT, qm = h.x >> 28;
+          const uint32_t base = cur & ~TILE_SPLIT, qm = h[u].x >> 28;
           const unsigned long long inc = (unsigned long long)((qm & 1u) | ((qm & 2u) << 15)) | ((unsigned long long)(((qm >> 2) & 1u) | ((qm & 8u) << 13)) << 32);
-          const unsigned long long at = atomicAdd(&qc[h.y], inc);
+          const unsigned long long at = atomicAdd(&qc[h[u].y], inc);
 #pragma unroll
           for (uint32_t q = 0; q < 4u; q++)
-            if ((qm >> q) & 1u) pent[base + ((uint32_t)(at >> (16u * q)) & 0xFFFFu)] = h.x;
+            if ((qm >> q) & 1u) pent[base + ((uint32_t)(at >> (16u * q)) & 0xFFFFu)] = h[u].x;
         }
       }
     }
@@ -269,7 +302,12 @@ bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint
   // threads per workgroup = triangles staged per round: 256; 128 for small frames (at most 64 tiles: 512 x 512 pixels), where a
   // triangle touches one tile or two -- the smaller window also keeps the lists closer to near-to-far order, which the
   // rasteriser's early-z lives on (320 x 200: set-up + binning 1.56 -> 1.50 ms, rasteriser 2.47 -> 2.33 ms)
-  const int bin_threads = rdoom::debug_options().bin_threads > 0 ? rdoom::debug_options().bin_threads : (tiles_x * tiles_y <= 64 ? 128 : 256);
+  // 512 for a large level rendered for few poses (BASELINE config 5's class: 36 k triangles, 256 poses at 4K): the kernel is one
+  // workgroup per pose walking the pose's visible triangles round by round -- with no more workgroups than CUs, twice the
+  // threads halve the rounds (set-up + binning 0.99 -> 0.76 ms there; on E1M1-sized levels the wider window costs the
+  // rasteriser's early-z more than it saves: measured, profiles/r05_ab.txt)
+  const int by_shape = tiles_x * tiles_y <= 64 ? 128 : ((cap >= 16384u && n_poses <= 512u) ? 512 : 256);
+  const int bin_threads = rdoom::debug_options().bin_threads > 0 ? rdoom::debug_options().bin_threads : by_shape;
   auto bk = bin_threads == 512 ? bin_kernel<512, 9> : (bin_threads == 128 ? bin_kernel<128, 7> : (bin_threads == 64 ? bin_kernel<64, 6> : bin_kernel<256, 8>));
   const int bt = bin_threads == 512 ? 512 : (bin_threads == 128 ? 128 : (bin_threads == 64 ? 64 : 256));
   // LDS budget: the kernel's static arrays plus a counter per tile must fit the 64 KiB a workgroup may use; frames

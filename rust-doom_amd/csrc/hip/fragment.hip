@@ -902,6 +902,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
       if (e < hdr.y) {
         rec = binned ? (entries[(size_t)pose * entry_cap + hdr.x + e] & ENTRY_REC_MASK) : sorted[(size_t)pose * cap + e].z;
         const RasterRec r = prec[rec].r;
+        const float *rwp = prec[rec].s.wp;  // (the 1/w plane lives in the shade part)
         const int x0 = (int)(r.bb0 & 0xFFFFu), y0 = (int)(r.bb0 >> 16), x1 = (int)(r.bb1 & 0xFFFFu),
                   y1 = (int)(r.bb1 >> 16);
         const float e0 = fmaf(r.e[0], px, fmaf(r.e[1], py, r.e[2])), e1 = fmaf(r.e[3], px, fmaf(r.e[4], py, r.e[5])),
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
         const bool in1 = (e1 > 0.0f) | ((e1 == 0.0f) & ((r.flags & (1u << 25)) != 0u));
         const bool in2 = (e2 > 0.0f) | ((e2 == 0.0f) & ((r.flags & (1u << 26)) != 0u));
         const float zw = fmaf(r.zp[0], px, fmaf(r.zp[1], py, r.zp[2]));
-        const float rw = fmaf(r.wp[0], px, fmaf(r.wp[1], py, r.wp[2]));
+        const float rw = fmaf(rwp[0], px, fmaf(rwp[1], py, rwp[2]));
         bool pass = (ix >= x0) & (ix <= x1) & (iy >= y0) & (iy <= y1) & in0 & in1 & in2 & (zw >= 0.0f) & (zw <= 1.0f) &
                     (rw > 0.0f);
         if (pass && (r.flags & RASTER_MASKED_ANY) != 0u) {

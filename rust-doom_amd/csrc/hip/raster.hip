@@ -323,9 +323,9 @@ __global__ __launch_bounds__(256) void settle_kernel(const TriRec *__restrict__ 
       }
     }
     if (best != NONE) {
-      const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[best]);
-      const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3];
-      const uint2 c4 = *reinterpret_cast<const uint2 *>(rp + 4);
+      uint4 c0, c1, c2, c3;
+      uint2 c4;
+      raster_words(&prec[best], c0, c1, c2, c3, c4);
       const float e0a = __uint_as_float(c0.x), e0b = __uint_as_float(c0.y), e0c = __uint_as_float(c0.z),
                   e1a = __uint_as_float(c0.w), e1b = __uint_as_float(c1.x), e1c = __uint_as_float(c1.y),
                   e2a = __uint_as_float(c1.z), e2b = __uint_as_float(c1.w), e2c = __uint_as_float(c2.x);
@@ -484,9 +484,9 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
       if (have) {
         const uint32_t myrec = e & ENTRY_REC_MASK;
         uint32_t myqb = e >> 28;
-        const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[myrec]);
-        const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2], c3 = rp[3];
-        const uint2 c4 = *reinterpret_cast<const uint2 *>(rp + 4);
+        uint4 c0, c1, c2, c3;
+        uint2 c4;
+        raster_words(&prec[myrec], c0, c1, c2, c3, c4);
         uint4 *mine = wrec[wave][lane];
         mine[0] = c0, mine[1] = c1, mine[2] = c3, mine[3] = make_uint4(c2.x, c4.x, c4.y, 0u);
         zpa = c2.y, zpb = c2.z, zpc = c2.w;

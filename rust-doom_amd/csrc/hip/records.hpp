@@ -55,15 +55,16 @@ struct alignas(16) ObjectConst {  // 144 bytes
 static_assert(sizeof(ObjectConst) == 144, "ObjectConst layout");
 
 // ---- per (pose, visible triangle) records -----------------------------------------------------
-struct alignas(16) RasterRec {  // 80 bytes
+// (round 5: 64 bytes -- the 1/w plane is the shade part's copy, ShadeRec::wp, which follows immediately: the rasteriser reads
+// the record's first five 16-byte words, c0..c2 = edges + depth plane, c3 = bbox + flags, c4 = (1/w plane, up[0]))
+struct alignas(16) RasterRec {  // 64 bytes
   float e[9];                   // edge functions A,B,C x3
   float zp[3];                  // window-depth plane
-  float wp[3];                  // 1/w plane
   uint32_t bb0, bb1;            // x0 | y0 << 16, x1 | y1 << 16 (inclusive)
   uint32_t flags;               // prim id (24 bits) | tl << 24 | kind << 27 | RASTER_MASKED_*
-  uint32_t pad[2];
+  uint32_t pad;
 };
-static_assert(sizeof(RasterRec) == 80 && offsetof(RasterRec, zp) == 36 && offsetof(RasterRec, bb0) == 60, "RasterRec layout");
+static_assert(sizeof(RasterRec) == 64 && offsetof(RasterRec, zp) == 36 && offsetof(RasterRec, bb0) == 48, "RasterRec layout");
 
 constexpr uint32_t RASTER_MASKED_BORDER = 1u << 29;    // a texel bordering the texture rectangle is transparent
 constexpr uint32_t RASTER_MASKED_INTERIOR = 1u << 30;  // the texture rectangle itself has transparent texels
@@ -83,11 +84,24 @@ struct alignas(16) ShadeRec {  // 64 bytes
 };
 static_assert(sizeof(ShadeRec) == 64, "ShadeRec layout");
 
-struct alignas(16) TriRec {  // 144 bytes = 9 x 16 B: what one (pose, visible triangle) carries
+// 128 bytes, 128-byte aligned: ONE cache line per record.  With the 144-byte record of rounds 1-4 every line of the record array
+// was shared by two records that different lanes, waves and workgroups of the set-up kernel store at different times (records go
+// to their depth rank): each line went to memory twice, partially filled -- and the set-up and binning kernels of the large-level
+// and small-frame workloads are bound by exactly this traffic (0.95 GB of records per step at 320 x 200 x 8 192 poses).
+struct alignas(128) TriRec {
   RasterRec r;
-  ShadeRec s;
+  ShadeRec s;  // s.wp is the 1/w plane of both parts
 };
-static_assert(sizeof(TriRec) == 144, "TriRec layout");
+static_assert(sizeof(TriRec) == 128 && offsetof(TriRec, s) == 64, "TriRec layout");
+// the rasteriser's five words of a record in the order its code names them (rounds 1-4's layout): c3 = (1/w plane, bb0),
+// c4 = (bb1, flags)
+__device__ __forceinline__ void raster_words(const TriRec *rec, uint4 &c0, uint4 &c1, uint4 &c2, uint4 &c3, uint2 &c4) {
+  const uint4 *rp = reinterpret_cast<const uint4 *>(rec);
+  c0 = rp[0], c1 = rp[1], c2 = rp[2];
+  const uint4 b = rp[3], w = rp[4];  // (bb0, bb1, flags, pad), (wp[0], wp[1], wp[2], up[0])
+  c3 = make_uint4(w.x, w.y, w.z, b.x);
+  c4 = make_uint2(b.y, b.z);
+}
 
 // Up to 32 consecutive triangles of one object with the bounding box of their vertices: the set-up kernel discards a
 // whole cluster when the box proves that every triangle in it fails S1 or S6 (corner arguments on the same fmaf chains).

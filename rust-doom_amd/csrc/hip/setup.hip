@@ -161,7 +161,7 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
             const float nu = fmaf(u[2], e2, fmaf(u[1], e1, u[0] * e0));
             const float nv = fmaf(v[2], e2, fmaf(v[1], e1, v[0] * e0));
             rr.zp[c] = 0.5f * (nz / det);
-            rr.wp[c] = n1 / det;
+            sr.wp[c] = n1 / det;
             sr.up[c] = nu / det;
             sr.vp[c] = nv / det;
           }
@@ -192,10 +192,7 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
           rr.bb1 = (uint32_t)x1 | ((uint32_t)y1 << 16);
           const uint32_t masked = (tri.packed >> 18) & 3u;  // border, interior
           rr.flags = (t & 0xFFFFFFu) | (tl << 24) | (kind << 27) | (masked << 29);
-          rr.pad[0] = rr.pad[1] = 0;
-          sr.wp[0] = rr.wp[0];
-          sr.wp[1] = rr.wp[1];
-          sr.wp[2] = rr.wp[2];
+          rr.pad = 0;
           sr.atlas_u = au;
           sr.atlas_v = av;
           sr.size_x = kind == RDOOM_KIND_SKY ? 4.0f * au / 3.14159265358f : tri.size_x;  // sky: the u shift of sky.frag:15
@@ -464,7 +461,7 @@ __global__ __launch_bounds__(256, RDOOM_SETUP_OCC) void setup_kernel(DeviceLevel
       const uint4 *v = reinterpret_cast<const uint4 *>(&rec);
       uint4 *dst = reinterpret_cast<uint4 *>(&prec[pos]);
 #pragma unroll
-      for (uint32_t k = 0; k < 9u; k++) dst[k] = v[k];
+      for (uint32_t k = 0; k < 8u; k++) dst[k] = v[k];
       psorted[pos] = make_uint4(rec.r.bb0, rec.r.bb1, pos, bucket);
     }
     __syncthreads();

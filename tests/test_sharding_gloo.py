@@ -126,5 +126,5 @@ def test_stream_plans():
     from util import ROOT
     sys.path.insert(0, ROOT)
     import bench
-    assert bench.resolve_streams(0, 1) == 2 and bench.resolve_streams(0, 9) == 3 and bench.resolve_streams(4, 9) == 4
-    assert bench.parts_per_level(1, 2) == 2 and bench.parts_per_level(9, 3) == 1 and bench.parts_per_level(2, 4) == 2 and bench.parts_per_level(1, 1) == 1
+    assert bench.resolve_streams(0, 1) == 3 and bench.resolve_streams(0, 9) == 3 and bench.resolve_streams(4, 9) == 4
+    assert bench.parts_per_level(1, 2) == 2 and bench.parts_per_level(1, 3) == 3 and bench.parts_per_level(9, 3) == 1 and bench.parts_per_level(2, 4) == 2 and bench.parts_per_level(1, 1) == 1
