@@ -570,20 +570,25 @@ def main():
     # per-step spread: an event at the end of every step on every render stream (GPU time stamps; nothing waits for them)
     mark_streams = tstreams if tstreams else [torch.cuda.current_stream()]
     ev_start = torch.cuda.Event(enable_timing=True)
+    # (the per-step marks exist before the timed region and the collector is off inside it: an allocation or a collection in the
+    # loop stalls the host for tens of milliseconds once in a few dozen steps -- seen as ONE 40 ms step in 20 on the nine-level
+    # workloads, whose renders are too short for the queue to ride such a pause out)
+    step_marks = [[torch.cuda.Event(enable_timing=True) for _ in mark_streams] for _ in range(args.steps)]
+    import gc
+    gc.collect()
+    gc.disable()
     ev_start.record(mark_streams[0])
-    step_marks = []
     t_start = time.perf_counter()
     acc = {'setup_ms': 0.0, 'raster_ms': 0.0, 'fragment_ms': 0.0}
     for i in range(args.steps):
         flush = step(i, None, timed_profiled)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in mark_streams]
-        for e, st in zip(marks, mark_streams):
+        for e, st in zip(step_marks[i], mark_streams):
             e.record(st)
-        step_marks.append(marks)
         if flush:
             collect(acc)   # (a host synchronisation every 60 steps)
     barrier()
     elapsed = time.perf_counter() - t_start
+    gc.enable()
     collect(acc)
     ends = [max(ev_start.elapsed_time(e) for e in marks) for marks in step_marks]   # ms since the start mark, per step
     step_ms = [b - a for a, b in zip([0.0] + ends[:-1], ends)]

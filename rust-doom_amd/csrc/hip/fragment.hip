@@ -1008,7 +1008,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
   const uint32_t wbpr = (qpr / (uint32_t)nq + bw - 1u) / bw, wbpp = wbpr * (((uint32_t)H + bh - 1u) / bh);  // bw-unit x bh-row blocks
   const uint32_t frag_chunk = plan.chunk;
   const uint32_t fblocks = (wbpp + frag_chunk * FRAG_WAVES - 1u) / (frag_chunk * FRAG_WAVES);  // a workgroup = FRAG_WAVES waves x frag_chunk blocks
-  HIP_TRY(hipMemsetAsync(fix_count, 0, 2 * sizeof(uint32_t), st));
+  // (fix_count[0..1] arrive zeroed: the caller's one fill at the start of the render)
   const uint64_t fgrid = (uint64_t)((n + 7) / 8) * 8ull * fblocks;
   if (fgrid > 0x7FFFFFFFull) return rdoom::fail(RDOOM_BAD_ARG, "batch too large for one launch");
   auto frag = nq == 2 ? (vis16 ? fragment_kernel<2, 0, true> : fragment_kernel<2, 0, false>)

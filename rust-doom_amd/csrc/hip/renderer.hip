@@ -62,6 +62,10 @@ struct rdoom_batch {
   uint2 *d_hits = nullptr;         // per pose: entry_cap (entry, tile) pairs: the binning kernel's count pass -> its fill pass
   uint32_t *d_overflow = nullptr;  // per pose: 1 = bins incomplete, rasteriser scans the sorted list
   uint32_t entry_cap = 0, n_tiles = 0;
+  // The words every render starts from zero -- d_fix_count (4), d_counts (max_poses), d_ghist (2048 per pose) -- are ONE
+  // allocation, d_zeroed, cleared by one hipMemsetAsync: four separate fills per render were four more packets between the
+  // kernels of a stream (the 1/8 share of config 4 queues 9 x 13 packets per step for a few hundred microseconds of work each).
+  uint32_t *d_zeroed = nullptr;
   uint32_t *d_fix_count = nullptr;  // [0] = queued pixels, [1] = error flag (fixup list overflow), [2] = error flag (the set-up kernel
                                     // disagreed with the cull kernel about a triangle: the counting sort's buckets would not add up)
   uint2 *d_fix_list = nullptr;
@@ -377,7 +381,7 @@ void rdoom_batch_destroy(rdoom_batch *b) {
   }
 #endif
   for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_visible, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries, (void *)b->d_hits,
-                  (void *)b->d_overflow, (void *)b->d_ghist, (void *)b->d_fix_count, (void *)b->d_fix_list, (void *)b->d_counts, (void *)b->d_vis,
+                  (void *)b->d_overflow, (void *)b->d_zeroed, (void *)b->d_fix_list, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb, (void *)b->d_qtab, b->d_frag_const})
     if (p) (void)hipFree(p);
   for (auto &e : b->ev)
@@ -433,10 +437,10 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_entries, sizeof(uint32_t) * (size_t)b->entry_cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_hits, sizeof(uint2) * (size_t)b->entry_cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_overflow, sizeof(uint32_t) * max_poses);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_count, 3 * sizeof(uint32_t));
+  const size_t counts_words = ((size_t)max_poses + 3u) & ~(size_t)3u;
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_zeroed, sizeof(uint32_t) * (4u + counts_words) + setup_histogram_bytes(max_poses));
+  if (e == hipSuccess) b->d_fix_count = b->d_zeroed, b->d_counts = b->d_zeroed + 4, b->d_ghist = b->d_zeroed + 4 + counts_words;
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fix_list, sizeof(uint2) * (size_t)b->fix_cap);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_counts, sizeof(uint32_t) * max_poses);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_ghist, setup_histogram_bytes(max_poses));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_vis, (b->vis16 ? sizeof(uint16_t) : sizeof(uint32_t)) * npx);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_fb, npx);
   if (e == hipSuccess) e = hipMalloc(&b->d_frag_const, fragment_const_bytes());
@@ -539,7 +543,8 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   HIP_TRY(hipEventRecord(b->ev_copy[sg], st));
   HT_MARK(2);
   const int W = (int)b->width, H = (int)b->height, PITCH = (int)b->pitch;
-  HIP_TRY(hipMemsetAsync(b->d_fix_count + 2, 0, sizeof(uint32_t), st));
+  // fix_count[0..2], the poses' visible-triangle counts and depth-bucket histograms (of the first n poses): one fill
+  HIP_TRY(hipMemsetAsync(b->d_zeroed, 0, (size_t)((const char *)b->d_ghist - (const char *)b->d_zeroed) + setup_histogram_bytes(n), st));
   if (lv->ntri)
     if (rdoom_status rs = launch_setup(st, n, lv->view, b->d_poses, object_modelviews ? (const ObjectConst *)b->d_objects : nullptr,
                                        lv->n_objects, W, H, kinds_mask, b->d_recs, b->d_visible, b->d_sorted, b->d_counts,
@@ -553,7 +558,6 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
                                b->entry_cap, b->d_hits, b->d_overflow, !rdoom::debug_options().no_split, &split_lists);
   if (!bins) {
     HIP_TRY(hipMemsetAsync(b->d_overflow, 0xFF, sizeof(uint32_t) * n, st));
-    if (!lv->ntri) HIP_TRY(hipMemsetAsync(b->d_counts, 0, sizeof(uint32_t) * n, st));
   }
   if (marks) HIP_TRY(hipEventRecord(ev[1], st));
   HT_MARK(4);

@@ -476,8 +476,7 @@ rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelVie
                           const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
                           TriRec *recs, uint32_t *visible, uint4 *sorted, uint32_t *counts, uint32_t *ghist, uint32_t cap,
                           uint32_t *mismatch_flag) {
-  HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_poses, st));
-  HIP_TRY(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * SORT_BUCKETS * (size_t)n_poses, st));
+  // (counts and ghist arrive zeroed: the caller clears them together with its other per-render words in one fill)
   // several workgroups per pose on large levels (each takes a share of the clusters): one would walk them serially
   const uint32_t groups = std::min<uint32_t>(std::max<uint32_t>(lv.n_clusters / 96u, 1u), 16u);
   hipLaunchKernelGGL(cull_kernel, dim3(groups, n_poses), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,

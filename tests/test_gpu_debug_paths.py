@@ -88,6 +88,18 @@ def test_rasteriser_without_the_two_entry_shortcut(hooks):
         assert bad == 0, (hooks, args)
 
 
+@pytest.mark.parametrize('hooks', [{'no_settle': 1}, {'settle_max': 1}, {'settle_max': 4}, {'settle_max': 64}, {'settle_max': 64, 'no_split': 1},
+                                   {'no_settle': 1, 'no_pair': 1}, {'settle_max': 8, 'no_pair': 1}, {'settle_max': 16, 'bin_threads': 512}])
+def test_settle_kernel_on_off_and_list_limits(hooks):
+    """settle_kernel (round 5) enters the one-triangle quadrants in the table before the rasteriser's waves start; tiles with
+    nothing left to do end at once, others pass only their TODO quadrants.  Off (no_settle), with list limits of 1 (only
+    one-entry lists), 4, 8, 16, 64 (every list that is stored whole), frames with partial tiles, many described quadrants (1080p)
+    and long lists (320 x 200): the rasteriser's own shortcut must agree with it everywhere -- same bytes."""
+    for args in (('0', '320', '200', '6'), ('0', '1920', '1080', '3'), ('5', '1000', '520', '3'), ('2', '1366', '768', '2')):
+        bad, _ = run_child(hooks, args)
+        assert bad == 0, (hooks, args)
+
+
 @pytest.mark.parametrize('size', [(322, 200), (1366, 768), (323, 131)])
 def test_padded_row_pitch_under_the_hooks(size):
     """widths that are not a multiple of 4 (padded row pitch) through the paths that address pixels on their own: the alpha-leak

@@ -115,6 +115,26 @@ def test_read_back_does_not_wait_for_another_threads_stream(oracle_levels):
     assert hip.hipStreamDestroy(sa) == 0 and hip.hipStreamDestroy(sb) == 0
 
 
+def test_bench_threads_launcher_on_this_gpu():
+    """`bench.py --gpus 2 --launcher threads`: one process, a host thread per GPU through the C ABI only (INTEGRATION.md's shape
+    for a Rust host) -- with one GPU present both threads wrap onto it; strong scaling: the two threads render the two halves of
+    ONE batch.  The line must account for every pose and say that it is not a scaling measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from util import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launcher', 'threads', '--scaling', 'strong', '--poses', '48',
+                          '--width', '640', '--height', '400', '--steps', '3', '--warmup', '1'], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['scaling'] == 'strong'
+    assert [r[:2] for r in line['config']['pose_ranges']] == [[0, 24], [24, 48]]
+    assert len(line['per_thread_ms_per_step']) == 2
+    if rd.device_count() < 2:
+        assert line['gpus_present'] == rd.device_count() and 'not a scaling measurement' in line['note']
+
+
 def test_last_error_is_thread_local(oracle_levels):
     lib = rd.lib()
     lib.rdoom_last_error.restype = ctypes.c_char_p

@@ -97,6 +97,38 @@ def test_framebuffer_pitch(oracle_levels):
         b.close()
 
 
+def test_path_stats(oracle_levels):
+    """rdoom_batch_path_stats: overflowed poses, split tile lists, described quadrants of the last render -- against what the
+    hooks force (entry_cap: every pose overflows; no_split: no split lists) and against the table's own arithmetic"""
+    lv = oracle_levels(0)
+    dev = rd.DeviceLevel(lv)
+    w, h, n = 320, 200, 6
+    poses = sweep_poses(lv, n, w, h)
+    lights = lv.lights.fill_buffer_at(0.0)
+    b = rd.Batch(dev, w, h, n)
+    b.render(poses, lights)
+    s = b.path_stats()
+    assert s['poses'] == n and s['bins_overflowed_poses'] == 0
+    assert s['tiles'] == n * 5 * 4 and s['quadrants'] == n * (10 * 7)         # 320x200: 5 x 4 tiles, 10 x 7 quadrants inside the frame (200 = 6.25 x 32)
+    assert 0 < s['described_quadrants'] < s['quadrants'] and s['tile_entries'] > s['tiles']
+    assert s['split_tiles'] > 0                                                # far tiles hold more than 64 entries at this size
+    fb = b.read_framebuffer()
+    try:
+        rd.debug_set('no_split', 1)
+        b.render(poses, lights)
+        s2 = b.path_stats()
+        assert s2['split_tiles'] == 0 and s2['tile_entries'] == s['tile_entries'] and s2['described_quadrants'] >= 1
+        assert np.array_equal(b.read_framebuffer(), fb)
+        rd.debug_set('reset', 0)
+        rd.debug_set('entry_cap', 300)
+        b2 = rd.Batch(dev, w, h, n)                                            # (entry_cap is read when a batch is created)
+        b2.render(poses, lights)
+        s3 = b2.path_stats()
+        assert s3['bins_overflowed_poses'] >= n - 1 and np.array_equal(b2.read_framebuffer(), fb)
+    finally:
+        rd.debug_set('reset', 0)
+
+
 def test_4k_time_varying(oracle_levels):
     """BASELINE config 5's frame size (3840x2160) with animated flats, scrolling walls and the per-pose light
     table at t != 0, on the synthetic E1M3 (no DOOM2.WAD exists here): 2040 tiles per frame, 8.3 Mpixel."""

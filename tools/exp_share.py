@@ -61,8 +61,11 @@ def variant(name, n_streams, parts, profiled, assign='part'):
             b.collect_timings()
     hip.hipDeviceSynchronize()
     t0 = time.perf_counter()
+    worst = 0.0
     for _ in range(a.steps):
+        ts = time.perf_counter()
         step()
+        worst = max(worst, time.perf_counter() - ts)
     t1 = time.perf_counter()
     hip.hipDeviceSynchronize()
     t2 = time.perf_counter()
@@ -73,7 +76,7 @@ def variant(name, n_streams, parts, profiled, assign='part'):
     for s in ss:
         if s.value:
             hip.hipStreamDestroy(s)
-    print('%-58s host enqueue %7.3f ms/step   step %7.3f ms' % (name, (t1 - t0) / a.steps * 1e3, (t2 - t0) / a.steps * 1e3), flush=True)
+    print('%-58s host enqueue %7.3f ms/step (slowest step %.2f ms)   step %7.3f ms' % (name, (t1 - t0) / a.steps * 1e3, worst * 1e3, (t2 - t0) / a.steps * 1e3), flush=True)
 
 
 variant('null stream, 1 part, plain', 0, 1, False)
