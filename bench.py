@@ -59,8 +59,8 @@ LAYOUT_READ_BYTES_PER_PIXEL = 4  # what this layout stores per pixel: a 16-bit v
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--poses', type=int, default=1024, help='poses per GPU (weak) or in total (strong), per level')
     ap.add_argument('--width', type=int, default=1920)
     ap.add_argument('--height', type=int, default=1080)

@@ -155,9 +155,18 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
   }
   __syncthreads();
   // blockIdx -> (pose, chunk): all chunks of a pose on one XCD (b % 8), like the rasteriser
+#ifdef RDOOM_FRAG_CHUNKS_OUTER
+  // (round 5 experiment, NOT the default: the rasteriser gained 11 % from dispatching its heavy tile rows first, raster.hip; the
+  // same order here -- a two-dimensional grid, the frame's chunks the slow dimension, the middle ones first -- measured 5 %
+  // SLOWER at 1080p and 9 % at 4K: a pose's visibility words and records are no longer walked while they are in its XCD's L2)
+  const uint32_t pose = blockIdx.x;
+  const uint32_t yk = blockIdx.y, yc = chunks_per_pose >> 1;
+  const uint32_t chunk = (yk & 1u) ? yc - ((yk + 1u) >> 1) : yc + (yk >> 1);  // c, c - 1, c + 1, c - 2, ...
+#else
   const uint32_t g = blockIdx.x >> 3;
   const uint32_t pose = (g / chunks_per_pose) * 8u + (blockIdx.x & 7u);
   const uint32_t chunk = g % chunks_per_pose;
+#endif
   if (pose >= n_poses) return;
   const TriRec *prec = recs + (size_t)pose * cap;
   constexpr uint32_t NONE_ID = VIS16 ? 0xFFFFu : NONE;
@@ -1032,7 +1041,13 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
     hipLaunchKernelGGL(fragment_quadrant_kernel, dim3((uint32_t)qgrid), dim3(256), 0, st, static_cast<const FragConst *>(d_frag_const), lv.texels,
                        lv.colormap, recs, cap, qtab, n, groups, (uint32_t)tiles_x, n_tiles, W, H, fb);
   }
-  hipLaunchKernelGGL(frag, dim3((uint32_t)fgrid), dim3(64 * FRAG_WAVES), 0, st, static_cast<const FragConst *>(d_frag_const), lv.texels,
+#ifdef RDOOM_FRAG_CHUNKS_OUTER
+  if (fblocks > 65535u) return rdoom::fail(RDOOM_BAD_ARG, "frame too large for one launch");
+  const dim3 fgrid_dim(((n + 7u) / 8u) * 8u, fblocks);
+#else
+  const dim3 fgrid_dim((uint32_t)fgrid);
+#endif
+  hipLaunchKernelGGL(frag, fgrid_dim, dim3(64 * FRAG_WAVES), 0, st, static_cast<const FragConst *>(d_frag_const), lv.texels,
                      lv.colormap, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp, qpr, wbpr, wbpp, bwl, W, H, fb, debug_leak_mod, qtab,
                      qtab_mode, (uint32_t)tiles_x, (uint32_t)(tiles_x * tiles_y));
   hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, pitch, H, tiles_x, tiles_y,

@@ -401,9 +401,21 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   // so blockIdx.x & 7 is the XCD and all tiles of a pose land on one of them; no division is needed to find (pose, tile)
   static_assert(RASTER_WAVES == 1, "the 3-D grid maps one tile to one workgroup");
   const uint32_t T = (uint32_t)(tiles_x * tiles_y);
+#ifndef RDOOM_RASTER_ROWS_INNER
+  // Tile ROWS are the slowest grid dimension, the frame's middle rows first (workgroups are dispatched x-fastest, then y, then z):
+  // the horizon rows hold the long lists, and a wave that walks 60 entries through four quadrants lives ten times longer than the
+  // average one -- dispatched with the last pose group it WAS the kernel's tail (a fixed ~0.1 ms per launch whatever the batch
+  // size, which the 128-pose renders of a strong-scaling share paid nine times per step).  Now every pose's heavy rows start
+  // first and the launch ends with the cheap rows (floor, ceiling, sky: mostly settled, their waves end after one load).
+  const uint32_t pose = blockIdx.y * 8u + (blockIdx.x & 7u);
+  const uint32_t zk = blockIdx.z, zc = (uint32_t)tiles_y >> 1;
+  const uint32_t tile_y = (zk & 1u) ? zc - ((zk + 1u) >> 1) : zc + (zk >> 1);  // c, c - 1, c + 1, c - 2, ...
+#else
   const uint32_t pose = blockIdx.z * 8u + (blockIdx.x & 7u);
+  const uint32_t tile_y = blockIdx.y;
+#endif
   const int tid = threadIdx.x, wave = 0, lane = tid & 63;
-  const uint32_t tile_x = blockIdx.x >> 3, tile_y = blockIdx.y, tile = tile_y * (uint32_t)tiles_x + tile_x;
+  const uint32_t tile_x = blockIdx.x >> 3, tile = tile_y * (uint32_t)tiles_x + tile_x;
   if (pose >= n_poses) return;
   RT_DECL
   const int tx0 = (int)tile_x * TILE_W, ty0 = (int)tile_y * TILE_H;
@@ -990,7 +1002,12 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
     hipLaunchKernelGGL(settle_kernel, dim3(((T4 + 255u) / 256u) * 8u, 1, groups), dim3(256), 0, st, recs, cap, n, width, height, tiles_x, tiles_y, tile_hdr,
                        entries, entry_cap, overflow, qtab, max_list);
   }
-  hipLaunchKernelGGL(rk, dim3((uint32_t)tiles_x * 8u, (uint32_t)tiles_y, groups), dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
+#ifndef RDOOM_RASTER_ROWS_INNER
+  const dim3 rgrid((uint32_t)tiles_x * 8u, groups, (uint32_t)tiles_y);
+#else
+  const dim3 rgrid((uint32_t)tiles_x * 8u, (uint32_t)tiles_y, groups);
+#endif
+  hipLaunchKernelGGL(rk, rgrid, dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, (dbg.no_cover ? 1u : 0u) | (dbg.no_pair ? 2u : 0u),
                      qtab, settle ? 1u : 0u, d_stats);
 #ifdef RDOOM_CENSUS_TWO

@@ -87,7 +87,7 @@ out = {'kernel': 'fragment_kernel', 'poses': bench['config']['poses_per_gpu'], '
        'hbm_read_bytes_per_launch': 2.0 * fetch * 1024.0, 'hbm_write_bytes_per_launch': write * 1024.0,
        'hbm_bytes_per_launch': 2.0 * fetch * 1024.0 + write * 1024.0,
        'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950, 16 B/lane reads)',
-       'round': rnd}
+       'round': rnd, 'taken': __import__('datetime').datetime.utcnow().strftime('%Y-%m-%d') + ' (round %d, tools/profile_round.sh)' % rnd}
 out['valu'] = valu_roofline(bench['config']['poses_per_gpu'] * bench['config']['width'] * bench['config']['height']) or None
 json.dump(out, open(os.path.join(dst, 'pmc_fragment_latest.json'), 'w'), indent=1)
 print(json.dumps(out))
@@ -108,10 +108,10 @@ for row in csv.DictReader(open(os.path.join(dst, 'r%02d_kernel_stats.csv' % rnd)
     md.append('| `%s` | %s | %.1f | %.1f %% |' % (name.replace('void ', ''), row['Calls'], float(row['AverageNs']) / 1e3, float(row['Percentage'])))
 trace = os.path.join(src, 'stats_default', 'r_kernel_trace.csv')
 if os.path.exists(trace):
-    rows = [r for r in csv.DictReader(open(trace)) if 'fragment_kernel' in r['Kernel_Name'] or 'raster_wave_kernel' in r['Kernel_Name']]
-    md += ['', '## the default command (two half-batches on two streams, then its single-stream pass over the whole batch): per-launch durations from the kernel trace', '',
-           '| kernel | launches | mean of the half-batch launches on two streams (warm-up + timed region; they overlap) us | mean of the last K launches (the single-stream pass: whole batch, one launch per step) us |', '|---|---|---|---|']
-    for key in ('fragment_kernel', 'raster_wave_kernel'):
+    rows = [r for r in csv.DictReader(open(trace)) if 'fragment_kernel' in r['Kernel_Name'] or 'raster_wave_kernel' in r['Kernel_Name'] or 'settle_kernel' in r['Kernel_Name']]
+    md += ['', '## the default command (sub-batches on the stream pool, then its single-stream pass over the whole batch): per-launch durations from the kernel trace', '',
+           '| kernel | launches | mean of the sub-batch launches on the pool (warm-up + timed region; they overlap) us | mean of the last K launches (the single-stream pass: whole batch, one launch per step) us |', '|---|---|---|---|']
+    for key in ('fragment_kernel', 'raster_wave_kernel', 'settle_kernel'):
         d = [(int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])) for r in rows if key in r['Kernel_Name']]
         d.sort()
         dur = [x[1] for x in d]
@@ -122,10 +122,24 @@ if os.path.exists(trace):
 md += ['', '## bench lines', '', '| workload | GPUs | Mpixel/s | frames/s | setup+bin / raster / fragment (ms) | fragment vs 6 B/px HBM-read roofline |',
        '|---|---|---|---|---|---|']
 for d in [bench] + lines:
-    k = d['config']['kernels_ms']
-    md.append('| %s%s | %d | %.0f | %.0f | %.2f / %.2f / %.2f | %.1f %% |' % (
-        d['config']['workload'], (' [%s scaling; %s]' % (d['scaling'], d.get('note', ''))) if d['n_gpus'] > 1 else '', d['n_gpus'], d['value'],
-        d['frames_per_s'], k['setup'], k['raster'], k['fragment'], 100.0 * d['roofline']['frac']))
+    k = d['config'].get('kernels_ms')   # (the threads launcher times whole steps only)
+    md.append('| %s%s%s | %d | %.0f | %.0f | %s | %s |' % (
+        d['config']['workload'], (' [%s scaling; %s]' % (d['scaling'], d.get('note', ''))) if d['n_gpus'] > 1 else '',
+        (' [launcher: %s]' % d['config']['launcher']) if 'launcher' in d['config'] else '', d['n_gpus'], d['value'],
+        d['frames_per_s'], ('%.2f / %.2f / %.2f' % (k['setup'], k['raster'], k['fragment'])) if k else '--',
+        ('%.1f %%' % (100.0 * d['roofline']['frac'])) if d.get('roofline') else '--'))
+    if d.get('scaling_proxy'):
+        sp = d['scaling_proxy']
+        md.append('| &nbsp;&nbsp;its 1/%d share (%d poses per level), 1 / 2 / 3 streams: %s ms per step; full batch %.3f ms -> predicted speed-up at %d GPUs %.2f (ideal share %.3f ms) | 1 | | | | |'
+                  % (sp['gpus'], sp['poses_per_level_share'], ' / '.join('%.3f' % sp['share_ms_by_streams'][s] for s in ('1', '2', '3')), sp['full_ms'], sp['gpus'],
+                     sp['predicted_speedup_at_%d' % sp['gpus']], sp['ideal_share_ms']))
+hooks = os.path.join(src, 'bench_hooks.jsonl')
+if os.path.exists(hooks):
+    shutil.copy(hooks, os.path.join(dst, 'r%02d_bench_hooks.jsonl' % rnd))
+    md += ['', '## the same box with this round\'s hooks (equivalent paths: same images)', '', '| hook | workload | Mpixel/s | ms per step | setup+bin / raster / fragment (ms) |', '|---|---|---|---|---|']
+    for d in [json.loads(x) for x in open(hooks)]:
+        k = d['config']['kernels_ms']
+        md.append('| %s | %s | %.0f | %.3f | %.2f / %.2f / %.2f |' % (' '.join(d['config'].get('debug', [])), d['config']['workload'][:90], d['value'], d['ms_per_step'], k['setup'], k['raster'], k['fragment']))
 frag_ms = bench['config']['kernels_ms']['fragment']
 md += ['', '## fragment kernel, HBM traffic (PMC, separate passes)', '',
        'FETCH_SIZE %.0f KiB x 2 (gfx950: wide reads counted half) = %.2f GB read, WRITE_SIZE %.0f KiB = %.2f GB written per launch; '

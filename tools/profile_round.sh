@@ -15,7 +15,7 @@ cd /tmp
 # (a) --streams 1: every kernel alone on the GPU, one launch per step -- the per-kernel accounting (rNN_kernel_stats.csv)
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o r --output-format csv -- python $ROOT/bench.py --streams 1 --other off > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
 echo "stats (--streams 1) rc=$?"
-# (b) the default command as it is (two half-batches on two streams, then its single-stream pass): launches are half-batches,
+# (b) the default command as it is (sub-batches on the stream pool, then its single-stream pass): launches are sub-batches,
 #     those of the timed region overlap (rNN_kernel_stats_default.csv + the kernel trace for tools/profile_collect.py)
 rocprofv3 --kernel-trace --stats -d $OUT/stats_default -o r --output-format csv -- python $ROOT/bench.py --other off > $OUT/bench_profiled_default.json 2> $OUT/bench_profiled_default.err
 echo "stats (default) rc=$?"
@@ -32,11 +32,19 @@ python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 tail -1 $OUT/bench_plain.json
 : > $OUT/bench_other.jsonl
 for ARGS in "--width 3840 --height 2160 --poses 256" "--width 1280 --height 720 --poses 2048" "--width 320 --height 200 --poses 8192" \
-            "--big" "--big --width 3840 --height 2160 --poses 256 --time-varying" "--levels 0-8 --poses 512" \
-            "--streams 1" "--streams 3" "--gpus 2" "--gpus 2 --scaling strong"; do
+            "--big" "--big --width 3840 --height 2160 --poses 256 --time-varying" "--levels 0-8 --share 8" \
+            "--streams 1" "--streams 2" "--width 1366 --height 768 --poses 2048" "--gpus 2" "--gpus 2 --scaling strong" \
+            "--gpus 2 --launcher threads --scaling strong"; do
   python bench.py $ARGS --steps 10 --warmup 2 --cpu-sample 0 --other off 2>/dev/null | grep '^{' | tail -1 >> $OUT/bench_other.jsonl
 done
 wc -l $OUT/bench_other.jsonl
 # 4. issue-slot / occupancy counters of the hot kernels on the final device sources
 bash tools/pmc_frag.sh $TAG/issue > $OUT/issue.log 2>&1
 find $OUT/issue -name '*counter_collection.csv' | wc -l
+# 5. A/B lines of the round's hooks on the same box (equivalent paths, same images): settle_kernel off / other list limits
+: > $OUT/bench_hooks.jsonl
+for ARGS in "--debug no_settle=1" "--debug settle_max=16" "--debug settle_max=64" "--width 3840 --height 2160 --poses 256 --debug no_settle=1" \
+            "--big --debug no_settle=1" "--width 320 --height 200 --poses 8192 --debug no_settle=1" "--levels 0-8 --debug no_settle=1"; do
+  python bench.py $ARGS --steps 10 --warmup 2 --cpu-sample 0 --other off 2>/dev/null | grep '^{' | tail -1 >> $OUT/bench_hooks.jsonl
+done
+wc -l $OUT/bench_hooks.jsonl
