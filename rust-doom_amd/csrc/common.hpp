@@ -17,7 +17,7 @@ struct DebugOptions {
   int vis32 = 0;         // 32-bit visibility words (the format of levels with >= 65535 triangles)
   int leak_mod = 0;      // every n-th pixel is queued as an alpha leak: fixup_kernel re-resolves ordinary pixels
   int frag_nq = 2;       // quads per lane in the fragment kernel (1 = the variant for widths that are not a multiple of 8)
-  int frag_bw = 3;       // log2(units per row of the fragment kernel's wave block)
+  int frag_bw = -1;      // log2(units per row of the fragment kernel's wave block); -1 = by frame size (fragment.hip: plan_fragment)
   int frag_chunk = 0;    // wave blocks per wave in the fragment kernel (0 = default)
   int bin_threads = 0;   // workgroup size of the binning kernel (0 = by frame size: bin.hip)
   int no_cover = 0;      // no depth-only body for quadrant-covering triangles

@@ -964,12 +964,16 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
 size_t fragment_const_bytes() { return sizeof(FragConst); }
 
 FragmentPlan plan_fragment(int width, int pitch, int height, bool have_qtab) {
-  (void)height;
   const rdoom::DebugOptions dbg = rdoom::debug_options();  // test hooks: equivalent paths, same image
   FragmentPlan p{};
   p.leak_mod = (uint32_t)std::max(0, dbg.leak_mod);
   p.nq = (dbg.frag_nq == 2 && pitch % 8 == 0) ? 2 : 1;  // quads per lane: two when rows (of `pitch` pixels) divide into 8-pixel runs
-  p.bwl = (uint32_t)std::min(6, std::max(0, dbg.frag_bw));  // log2(units per block row)
+  // log2(units per block row).  By default a wave's block is 4 runs x 16 rows (32 x 16 pixels, inside ONE quadrant of the
+  // rasteriser's table) for frames of 1280 x 720 and up, 8 runs x 8 rows (64 x 8, two quadrants side by side) below: measured on
+  // one box in round 5 -- 4K 596 -> 620 Gpixel/s, E1M1..E1M9 at 1080p 508 -> 523, 1080p 487 -> 491, 720p alike, 320 x 200
+  // 119 -> 116 (profiles/r05_ab.txt); rounds 3-4 ran 64 x 8 everywhere.
+  const int bw_auto = (size_t)pitch * (size_t)height >= (size_t)1280 * 720 ? 2 : 3;
+  p.bwl = (uint32_t)std::min(6, dbg.frag_bw >= 0 ? dbg.frag_bw : bw_auto);
   p.chunk = dbg.frag_chunk > 0 ? (uint32_t)dbg.frag_chunk : (uint32_t)FRAG_CHUNK;
   // the quadrant table serves blocks that lie inside one 32 x 32 quadrant, or inside two side by side
   const uint32_t bw = 1u << p.bwl, bh = 64u >> p.bwl, block_px = bw * 4u * (uint32_t)p.nq;

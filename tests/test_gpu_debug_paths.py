@@ -7,7 +7,8 @@ process sets its own, they are process-wide).  Every hook selects an equivalent 
   frag_nq=1      one quad per lane in the fragment kernel (default two when the width is a multiple of 8);
   vis32=1        32-bit visibility words (levels with >= 65535 triangles) instead of 16-bit ones;
   no_cover=1     the rasteriser without its depth-only body for quadrant-covering triangles;
-  frag_bw=k      the fragment kernel's wave block is 2^k units wide (default 3: 64 x 8 pixels);
+  frag_bw=k      the fragment kernel's wave block is 2^k units wide (default: 2 = 32 x 16 pixels for frames of 1280 x 720 and up,
+                 3 = 64 x 8 below);
   no_qtab=1      the fragment kernel ignores the rasteriser's quadrant table ("every pixel of this 32 x 32 quadrant shows
                  record r") and reads the visibility words of every block, as it did before the table existed;
   keep_vis=1     the rasteriser writes the visibility words of every quadrant, also of those its table describes (by default it
@@ -98,6 +99,15 @@ def test_settle_kernel_on_off_and_list_limits(hooks):
     for args in (('0', '320', '200', '6'), ('0', '1920', '1080', '3'), ('5', '1000', '520', '3'), ('2', '1366', '768', '2')):
         bad, _ = run_child(hooks, args)
         assert bad == 0, (hooks, args)
+
+
+@pytest.mark.parametrize('args', [('0', '1920', '1080', '3'), ('3', '1280', '720', '3'), ('6', '640', '400', '3')])
+def test_both_default_block_shapes_at_every_size(args):
+    """the fragment kernel's default wave block is 32 x 16 pixels from 1280 x 720 up and 64 x 8 below (round 5): each shape at the
+    sizes where the other is the default"""
+    for bw in (2, 3):
+        bad, _ = run_child({'frag_bw': bw}, args)
+        assert bad == 0, (bw, args)
 
 
 @pytest.mark.parametrize('size', [(322, 200), (1366, 768), (323, 131)])
