@@ -738,6 +738,10 @@ def main():
             'value_spread': {'step_ms_min': round(min(step_ms), 3), 'step_ms_median': round(float(np.median(step_ms)), 3),
                              'step_ms_max': round(max(step_ms), 3),
                              'value_min': round(my_px_per_step * world / max(step_ms) / 1e3, 1), 'value_max': round(my_px_per_step * world / min(step_ms) / 1e3, 1),
+                             # (the first step after the opening barrier starts on an empty GPU and pays the set-up chain's latency
+                             # un-overlapped; the last one drains alone: the mean over K steps carries both, the median does not)
+                             'step_ms_first': round(step_ms[0], 3), 'step_ms_last': round(step_ms[-1], 3),
+                             'value_at_median_step': round(my_px_per_step * world / float(np.median(step_ms)) / 1e3, 1),
                              'from': 'rank 0, one event per step and render stream'},
             'roofline': {'bound': 'hbm', 'kernel': 'fragment_kernel', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
