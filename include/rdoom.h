@@ -180,7 +180,9 @@ void rdoom_batch_destroy(rdoom_batch *batch);
 /* replaces the frame.draw loop of Renderer::update (engine/src/renderer.rs:98-157) for n_poses
  * frames at once.  lights: n_poses tables of 256 bytes (Lights::fill_buffer_at, game/src/lights.rs:26-30)
  * spaced lights_stride bytes apart (0 = one shared table).  kinds_mask selects draw kinds.
- * Asynchronous on `stream` (a hipStream_t, may be NULL); results stay on the device. */
+ * Asynchronous on `stream` (a hipStream_t, may be NULL); results stay on the device.  A batch's scratch is written by every
+ * render: consecutive renders of ONE batch must be ordered -- the same stream, or streams the caller orders -- and the host may
+ * queue two of them before it waits for the first one's pose copy (pinned staging, two deep). */
 rdoom_status rdoom_batch_render(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
                                 uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream);
 /* same, with per-kernel hipEvent timing (synchronises the stream) */
