@@ -972,7 +972,8 @@ FragmentPlan plan_fragment(int width, int pitch, int height, bool have_qtab) {
   // rasteriser's table) for frames of 1280 x 720 and up, 8 runs x 8 rows (64 x 8, two quadrants side by side) below: measured on
   // one box in round 5 -- 4K 596 -> 620 Gpixel/s, E1M1..E1M9 at 1080p 508 -> 523, 1080p 487 -> 491, 720p alike, 320 x 200
   // 119 -> 116 (profiles/r05_ab.txt); rounds 3-4 ran 64 x 8 everywhere.
-  const int bw_auto = (size_t)pitch * (size_t)height >= (size_t)1280 * 720 ? 2 : 3;
+  // (a row pitch that is a multiple of 4 but not of 8 leaves one quad per lane: its 32-pixel block is 8 units wide whatever the frame)
+  const int bw_auto = (p.nq == 2 && (size_t)pitch * (size_t)height >= (size_t)1280 * 720) ? 2 : 3;
   p.bwl = (uint32_t)std::min(6, dbg.frag_bw >= 0 ? dbg.frag_bw : bw_auto);
   p.chunk = dbg.frag_chunk > 0 ? (uint32_t)dbg.frag_chunk : (uint32_t)FRAG_CHUNK;
   // the quadrant table serves blocks that lie inside one 32 x 32 quadrant, or inside two side by side

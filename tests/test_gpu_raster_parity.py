@@ -81,7 +81,8 @@ def test_any_window_size(oracle_levels):
     rows below the frame in their bottom block row (raster.hip: they start at depth 0).  1366x768 and 1600x900 are the sizes the
     round-4 review names; 322 / 321 / 323 pad by 6 / 7 / 5 columns (a whole 4-pixel block of padding in the first two)."""
     lv = oracle_levels(1)
-    for w, h, n in ((322, 200, 4), (321, 199, 3), (323, 130, 3), (1366, 768, 2), (1600, 900, 2), (1921, 1082, 1), (5, 3, 2), (9, 70, 2)):
+    for w, h, n in ((322, 200, 4), (321, 199, 3), (323, 130, 3), (1366, 768, 2), (1600, 900, 2), (1921, 1082, 1), (5, 3, 2), (9, 70, 2),
+                    (1284, 724, 2)):   # (a large frame whose pitch is a multiple of 4 only: one quad per lane, 32 x 16 blocks all the same)
         run_case(lv, w, h, n, rd.ALL_KINDS)
     lv = oracle_levels(0)
     run_case(lv, 1366, 768, 3, rd.ALL_KINDS, time=0.9)
