@@ -173,7 +173,7 @@ OTHER_WORKLOADS = (   # BASELINE configs 2 / 4 / 5 (and the 4K frame) in short: 
 )
 
 
-def quick_line(rd, torch, sharding, wad, spec, streams, steps=8, warmup=2, kernels=True):
+def quick_line(rd, torch, sharding, wad, spec, streams, steps=12, warmup=3, kernels=True):
     """One short measurement of another workload, timed like the headline: the renders of a step spread over `streams` HIP
     streams (value), then every level as ONE batch on one stream for the per-kernel times (kernels=False: skipped)."""
     w, h, n = spec['width'], spec['height'], spec['poses']
@@ -248,7 +248,7 @@ def quick_line(rd, torch, sharding, wad, spec, streams, steps=8, warmup=2, kerne
     return out
 
 
-def scaling_proxy(rd, torch, sharding, wad, spec, G, full_line, steps=8, warmup=2):
+def scaling_proxy(rd, torch, sharding, wad, spec, G, full_line, steps=20, warmup=3):
     """The strong-scaling share a one-GPU box can measure: the workload of `spec` with poses / G per level -- what ONE of G GPUs renders
     under --scaling strong (its contiguous range of every level's batch) -- timed like the full batch, on 1, 2 and 3 streams.
     predicted_speedup_at_G = full step time / best share step time: the speed-up G GPUs would give IF each did as well on its
@@ -652,7 +652,9 @@ def main():
                     wads[key] = rd.Wad(synthetic.ensure_big_wad() if key else synthetic.ensure_wad(), synthetic.META_PATH)
                 try:
                     ws = 1 if cli_streams == 1 else spec.get('streams', resolve_streams(0, len(spec['levels'])))   # (--streams 1: everything on one stream)
-                    line = quick_line(rd, torch, sharding, wads[key], spec, ws)
+                    # (the line a strong-scaling share is compared with gets as many steps as the share: the first step after a
+                    # synchronisation starts on an empty GPU, and that ramp weighs more on a 5 ms step than on a 37 ms one)
+                    line = quick_line(rd, torch, sharding, wads[key], spec, ws, **({'steps': 20} if spec.get('share') else {}))
                     if spec.get('share'):   # the strong-scaling share a one-GPU box can time (BASELINE config 4 is strong scaling)
                         line['scaling_proxy'] = scaling_proxy(rd, torch, sharding, wads[key], spec, spec['share'], line)
                     other_lines.append(line)
