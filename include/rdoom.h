@@ -169,6 +169,15 @@ rdoom_status rdoom_set_device(int32_t device);
  * (engine/src/meshes.rs:126-201, engine/src/uniforms.rs:146-221) */
 rdoom_status rdoom_level_create(const rdoom_level_desc *desc, rdoom_level **out_level);
 void rdoom_level_destroy(rdoom_level *level);
+/* Several levels resident together, as ONE rdoom_level handle (rdoom_level_create = a set of one): a pose batch may then mix
+ * poses of different levels in one render (rdoom_batch_render_levels) -- one launch set for, say, the 9 x 128 poses one of eight
+ * GPUs renders of E1M1..E1M9 instead of nine small ones.  The reference keeps one level loaded at a time and draws it frame by
+ * frame (game/src/level.rs:330-496 builds and uploads it, engine/src/renderer.rs:98-157 is the draw loop); this replaces N of
+ * those uploads.  The levels must come from one IWAD: their COLORMAP tables must be identical (wad/src/tex.rs:137-166 reads the
+ * archive's one COLORMAP lump).  Primitive ids, object ids and light tables stay per level.  At most 2^26 atlas texels in the set. */
+rdoom_status rdoom_levelset_create(const rdoom_level_desc *const *descs, uint32_t n_levels, rdoom_level **out_level);
+/* how many levels the handle holds (1 for rdoom_level_create) */
+rdoom_status rdoom_level_num_levels(const rdoom_level *level, uint32_t *out);
 
 /* allocates the device scratch for up to max_poses frames of width x height -- any size up to 16384 on a side, as the
  * reference's --resolution WxH (src/main.rs:41).  Rows of the device framebuffer are rdoom_batch_framebuffer_pitch bytes
@@ -204,7 +213,17 @@ rdoom_status rdoom_batch_collect_timings(rdoom_batch *batch, rdoom_timings *out_
 rdoom_status rdoom_batch_render_objects(rdoom_batch *batch, const rdoom_pose *poses, const uint8_t *lights,
                                         uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
                                         const float *object_modelviews, uint32_t n_objects);
-/* 1 + the largest rdoom_draw.object_id of the level */
+/* rdoom_batch_render / _objects / _profiled for a batch created on a level SET: pose p is a view of level level_of_pose[p]
+ * (an index into the descs of rdoom_levelset_create), lights + p * lights_stride is THAT level's light table at the pose's time.
+ * object_modelviews may be NULL (no moving objects); else n_poses x n_objects matrices as for rdoom_batch_render_objects, with
+ * n_objects >= rdoom_level_num_objects of the set (entries of objects the pose's level does not draw are ignored).
+ * flags: RDOOM_RENDER_PROFILED keeps the per-kernel events pending as rdoom_batch_render_profiled does.
+ * Replaces the frame.draw loops of Renderer::update (engine/src/renderer.rs:98-157) of SEVERAL loaded levels at once. */
+#define RDOOM_RENDER_PROFILED 1u
+rdoom_status rdoom_batch_render_levels(rdoom_batch *batch, const rdoom_pose *poses, const uint32_t *level_of_pose, const uint8_t *lights,
+                                       uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
+                                       const float *object_modelviews, uint32_t n_objects, uint32_t flags);
+/* 1 + the largest rdoom_draw.object_id of the level (of a set: of any of its levels) */
 rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out);
 /* Waits for the batch's last render -- on the stream it was queued on; work of other batches on other streams is not waited
  * for -- and returns ITS status: the asynchronous rdoom_batch_render cannot report what only
@@ -224,7 +243,7 @@ rdoom_status rdoom_batch_framebuffer_pitch(const rdoom_batch *batch, uint32_t *o
 /* glReadPixels analogue: waits for the batch's last render (on its stream -- not for the device), copies frames
  * [first, first+count) to host memory, tightly packed (width bytes per row) */
 rdoom_status rdoom_batch_read_framebuffer(rdoom_batch *batch, uint32_t first, uint32_t count, uint8_t *host_out);
-/* Debug / test facility: capture the winning primitive id per pixel (global triangle index in draw order,
+/* Debug / test facility: capture the winning primitive id per pixel (triangle index in the draw order of the pose's level,
  * 0xFFFFFFFF = none) on the following renders, then read it back.  No GL counterpart. */
 rdoom_status rdoom_batch_enable_primitive_ids(rdoom_batch *batch);
 rdoom_status rdoom_batch_read_primitive_ids(rdoom_batch *batch, uint32_t first, uint32_t count, uint32_t *host_out);

@@ -86,7 +86,8 @@ API_SYMBOLS = [
     'rdoom_wad_name_from_bytes', 'rdoom_wad_build_level', 'rdoom_built_destroy', 'rdoom_built_desc',
     'rdoom_built_counters', 'rdoom_built_lights_at', 'rdoom_built_start', 'rdoom_built_floor_centroids',
     'rdoom_pose_look', 'rdoom_selftest_fastmath', 'rdoom_debug_set', 'rdoom_wad_walk', 'rdoom_wad_build_level_chained', 'rdoom_batch_render_objects', 'rdoom_level_num_objects', 'rdoom_batch_enable_primitive_ids',
-    'rdoom_wad_timings', 'rdoom_built_timings', 'rdoom_pose_from_player', 'rdoom_batch_framebuffer_pitch', 'rdoom_batch_path_stats']
+    'rdoom_wad_timings', 'rdoom_built_timings', 'rdoom_pose_from_player', 'rdoom_batch_framebuffer_pitch', 'rdoom_batch_path_stats',
+    'rdoom_levelset_create', 'rdoom_level_num_levels', 'rdoom_batch_render_levels']
 
 _lib = None
 
@@ -435,6 +436,31 @@ class DeviceLevel:
         _close_quietly(self)
 
 
+class DeviceLevelSet(DeviceLevel):
+    """Several levels resident in HBM as ONE handle (rdoom_levelset_create): a Batch created on it renders poses of different
+    levels in one launch set (Batch.render(..., level_of_pose=...)).  `sources`: BuiltLevel / LevelDesc / array dicts."""
+
+    def __init__(self, sources):
+        descs, self._keep = [], []
+        for source in sources:
+            if isinstance(source, BuiltLevel):
+                desc, keep = source.desc, source
+            elif isinstance(source, LevelDesc):
+                desc, keep = source, None
+            else:
+                desc, keep = make_desc(source)
+            descs.append(desc)
+            self._keep.append((desc, keep))
+        arr = (ctypes.POINTER(LevelDesc) * len(descs))(*[ctypes.pointer(d) for d in descs])
+        self._h = ctypes.c_void_p()
+        _check(lib().rdoom_levelset_create(arr, len(descs), ctypes.byref(self._h)))
+
+    def num_levels(self):
+        n = ctypes.c_uint32()
+        _check(lib().rdoom_level_num_levels(self._h, ctypes.byref(n)))
+        return n.value
+
+
 class Batch:
     """A pose batch: device scratch + the three kernels (setup, tiled raster, fragment)."""
 
@@ -463,10 +489,24 @@ class Batch:
             stride = 256
         return poses, lights, stride
 
-    def render_profiled(self, poses, lights, kinds=ALL_KINDS, stream=None):
+    def _render_levels(self, poses, lights, stride, kinds, stream, level_of_pose, object_modelviews, profiled):
+        lop = np.ascontiguousarray(level_of_pose, np.uint32).reshape(-1)
+        assert len(lop) == len(poses), 'level_of_pose: one level index per pose'
+        om, n_obj = None, 0
+        if object_modelviews is not None:
+            om = np.ascontiguousarray(object_modelviews, np.float32).reshape(len(poses), -1, 16)
+            n_obj = om.shape[1]
+        _check(lib().rdoom_batch_render_levels(
+            self._h, poses.ctypes.data_as(ctypes.c_void_p), lop.ctypes.data_as(ctypes.c_void_p), lights.ctypes.data_as(ctypes.c_void_p),
+            stride, len(poses), int(kinds), ctypes.c_void_p(stream or 0), om.ctypes.data_as(ctypes.c_void_p) if om is not None else None,
+            n_obj, 1 if profiled else 0))
+
+    def render_profiled(self, poses, lights, kinds=ALL_KINDS, stream=None, level_of_pose=None):
         """rdoom_batch_render_profiled: asynchronous, the per-kernel events stay pending (at most 64 renders)"""
         poses, lights, stride = self._prep(poses, lights)
         self.last_n = len(poses)
+        if level_of_pose is not None:
+            return self._render_levels(poses, lights, stride, kinds, stream, level_of_pose, None, True)
         _check(lib().rdoom_batch_render_profiled(self._h, poses.ctypes.data_as(ctypes.c_void_p), lights.ctypes.data_as(ctypes.c_void_p),
                                                  stride, len(poses), int(kinds), ctypes.c_void_p(stream or 0)))
 
@@ -478,11 +518,15 @@ class Batch:
         out['renders'] = n.value
         return out
 
-    def render(self, poses, lights, kinds=ALL_KINDS, stream=None, timed=False, object_modelviews=None):
+    def render(self, poses, lights, kinds=ALL_KINDS, stream=None, timed=False, object_modelviews=None, level_of_pose=None):
         """rdoom_batch_render(_timed): asynchronous unless timed; returns Timings fields when timed.
-        object_modelviews: optional (n_poses, n_objects, 16) u_modelview per object -> rdoom_batch_render_objects."""
+        object_modelviews: optional (n_poses, n_objects, 16) u_modelview per object -> rdoom_batch_render_objects.
+        level_of_pose: (n_poses,) level index of every pose, for a batch on a DeviceLevelSet -> rdoom_batch_render_levels."""
         poses, lights, stride = self._prep(poses, lights)
         self.last_n = len(poses)
+        if level_of_pose is not None:
+            assert not timed, 'timed renders of a level set: use render_profiled + collect_timings'
+            return self._render_levels(poses, lights, stride, kinds, stream, level_of_pose, object_modelviews, False)
         if object_modelviews is not None:
             om = np.ascontiguousarray(object_modelviews, np.float32).reshape(len(poses), -1, 16)
             _check(lib().rdoom_batch_render_objects(

@@ -295,10 +295,12 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
 
 }  // namespace
 
-bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
-                uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
-                uint2 *hits, uint32_t *overflow, bool want_split, bool *used_split) {
+rdoom_status launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
+                        uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
+                        uint2 *hits, uint32_t *overflow, bool want_split, bool *launched, bool *used_split) {
+  *launched = false, *used_split = false;
   const uint32_t bin_tiles = std::min<uint32_t>((uint32_t)(tiles_x * tiles_y), MAX_TILES);
+  if ((uint32_t)(tiles_x * tiles_y) > MAX_TILES) return RDOOM_OK;
   // threads per workgroup = triangles staged per round: 256; 128 for small frames (at most 64 tiles: 512 x 512 pixels), where a
   // triangle touches one tile or two -- the smaller window also keeps the lists closer to near-to-far order, which the
   // rasteriser's early-z lives on (320 x 200: set-up + binning 1.56 -> 1.50 ms, rasteriser 2.47 -> 2.33 ms)
@@ -307,32 +309,50 @@ bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint
   // threads halve the rounds (set-up + binning 0.99 -> 0.76 ms there; on E1M1-sized levels the wider window costs the
   // rasteriser's early-z more than it saves: measured, profiles/r05_ab.txt)
   const int by_shape = tiles_x * tiles_y <= 64 ? 128 : ((cap >= 16384u && n_poses <= 512u) ? 512 : 256);
-  const int bin_threads = rdoom::debug_options().bin_threads > 0 ? rdoom::debug_options().bin_threads : by_shape;
-  auto bk = bin_threads == 512 ? bin_kernel<512, 9> : (bin_threads == 128 ? bin_kernel<128, 7> : (bin_threads == 64 ? bin_kernel<64, 6> : bin_kernel<256, 8>));
-  const int bt = bin_threads == 512 ? 512 : (bin_threads == 128 ? 128 : (bin_threads == 64 ? 64 : 256));
-  // LDS budget: the kernel's static arrays plus a counter per tile must fit the 64 KiB a workgroup may use; frames
-  // with more tiles than that (7680x4320 and up) are rasterised from the sorted list instead
-  static std::atomic<size_t> static_lds[4];  // per variant, asked once (a constant of the compiled kernel); 0 = not asked yet
-  std::atomic<size_t> &slot = static_lds[bin_threads == 512 ? 2 : (bin_threads == 128 ? 1 : (bin_threads == 64 ? 3 : 0))];
-  size_t lds = slot.load(std::memory_order_relaxed);
-  if (lds == 0) {
-    hipFuncAttributes attr;
-    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(bk)) != hipSuccess) return false;
-    lds = attr.sharedSizeBytes + 1;
-    slot.store(lds, std::memory_order_relaxed);
-  }
+  const bool forced = rdoom::debug_options().bin_threads > 0;
+  int bin_threads = forced ? rdoom::debug_options().bin_threads : by_shape;
+  if (bin_threads != 512 && bin_threads != 128 && bin_threads != 64) bin_threads = 256;
   // (the dynamic segment as it is REQUESTED: a counter per tile, two more with split lists, and 8 bytes that keep the 64-bit
   // words of the split lists' counters aligned -- the same number in the budget test and in the launch)
   auto dyn_bytes = [&](bool with_split) { return (with_split ? 3 : 1) * sizeof(uint32_t) * (size_t)bin_tiles + 8u; };
-  if ((lds - 1) + dyn_bytes(false) > 65536u || (uint32_t)(tiles_x * tiles_y) > MAX_TILES) return false;
+  // LDS budget: the kernel's static arrays plus a counter per tile must fit the 64 KiB a workgroup may use; frames
+  // with more tiles than that (7680x4320 and up) are rasterised from the sorted list instead
+  static std::atomic<size_t> static_lds[4];  // per variant, asked once (a constant of the compiled kernel); 0 = not asked yet
+  auto variant = [&](int threads, size_t *static_bytes) {
+    auto k = threads == 512 ? bin_kernel<512, 9> : (threads == 128 ? bin_kernel<128, 7> : (threads == 64 ? bin_kernel<64, 6> : bin_kernel<256, 8>));
+    std::atomic<size_t> &slot = static_lds[threads == 512 ? 2 : (threads == 128 ? 1 : (threads == 64 ? 3 : 0))];
+    size_t lds = slot.load(std::memory_order_relaxed);
+    if (lds == 0) {
+      hipFuncAttributes attr;
+      if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k)) != hipSuccess) {
+        *static_bytes = ~(size_t)0 >> 1;
+        return k;
+      }
+      lds = attr.sharedSizeBytes + 1;
+      slot.store(lds, std::memory_order_relaxed);
+    }
+    *static_bytes = lds - 1;
+    return k;
+  };
+  size_t static_bytes = 0;
+  auto bk = variant(bin_threads, &static_bytes);
+  // The 512-thread variant holds twice the static LDS of the 256-thread one (33 KiB against 17): at very large frames it fails
+  // the budget -- or keeps whole-tile lists where 256 threads would still split the long ones -- while the narrower kernel fits.
+  // The automatic choice then falls back to 256 threads rather than to the sorted-list rasteriser (a forced choice stays).
+  if (!forced && bin_threads == 512 && static_bytes + dyn_bytes(want_split) > 65536u) {
+    bin_threads = 256;
+    bk = variant(bin_threads, &static_bytes);
+  }
+  if (static_bytes + dyn_bytes(false) > 65536u) return RDOOM_OK;  // not launched: the caller flags every pose as "bins incomplete"
   // split lists need two more counters per tile (frames beyond ~4 000 tiles -- 5K and up -- keep whole-tile lists)
-  const bool split = want_split && (lds - 1) + dyn_bytes(true) <= 65536u;
-  *used_split = split;
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bt), dyn_bytes(split), st, recs, sorted, counts, cap, tiles_x,
+  const bool split = want_split && static_bytes + dyn_bytes(true) <= 65536u;
+  hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bin_threads), dyn_bytes(split), st, recs, sorted, counts, cap, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, hits, overflow, split ? 1u : 0u);
-  if (hipGetLastError() != hipSuccess) return false;  // not launched: the caller flags every pose as "bins incomplete"
-  return true;
+  // (launch_setup ended with a check of its own launches: an error here is this launch's.  It is REPORTED, not turned into
+  // "bins incomplete": the configuration was validated above, so a failure means the device or the queue is in trouble)
+  HIP_TRY(hipGetLastError());
+  *launched = true, *used_split = split;
+  return RDOOM_OK;
 }
 
 }  // namespace rdoom_dev

@@ -67,7 +67,7 @@ typedef uint32_t TexelWord __attribute__((aligned(2)));
 #define FRAG_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RDOOM_FRAG_OCC, 8)))
 constexpr int FRAG_WLIST = 160;  // per-wave list of unfinished quads: at most 15 carried over + 64 x 2 new
 
-__device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const uint8_t *cmap, float px, float py,
+__device__ __forceinline__ uint32_t shade_sky(const LevelSlice &lv, const uint16_t *__restrict__ sky_texels, const uint8_t *cmap, float px, float py,
                                               int width, int height, float vr0, float vr1) {
   const float ndc_x = px / (0.5f * (float)width) - 1.0f;
   const float ndc_y = py / (0.5f * (float)height) - 1.0f;
@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t shade_sky(const DeviceLevelView &lv, const u
   int ix = (int)floorf(fx * (float)lv.sky_w), iy = (int)floorf(fy * (float)lv.sky_h);
   if (ix >= (int)lv.sky_w) ix = (int)lv.sky_w - 1;
   if (iy >= (int)lv.sky_h) iy = (int)lv.sky_h - 1;
-  const uint32_t texel = lv.sky_tex[(size_t)iy * lv.sky_w + (size_t)ix];
+  const uint32_t texel = sky_texels[(size_t)lv.sky_base + (size_t)iy * lv.sky_w + (size_t)ix];
   return cmap[texel & 0xFFu];
 }
 
@@ -100,9 +100,9 @@ __device__ __forceinline__ uint32_t shade_pixel(const DeviceLevelView &lv, const
                                                 float px, float py, float row_w, float row_u, float row_v,
                                                 int width, int height, const PoseConst &pc) {
   const uint32_t kind = s.flags & 3u;
-  if (kind == RDOOM_KIND_SKY) return shade_sky(lv, cmap, px, py, width, height, s.atlas_u, s.atlas_v);
+  if (kind == RDOOM_KIND_SKY) return shade_sky(lv.slices[pc.level], lv.sky_texels, cmap, px, py, width, height, s.atlas_u, s.atlas_v);
   const TexelAt t = texel_coords<IN_RANGE>(s, px, row_w, row_u, row_v);
-  const uint32_t texel = load_texel(lv, s, t.ix, t.iy);
+  const uint32_t texel = load_texel(lv.texels, s, t.ix, t.iy);
   if (kind != RDOOM_KIND_FLAT && (texel & 0x8000u)) return 0x100u;
   float light;
   if (kind == RDOOM_KIND_DECOR) {  // sprite.frag:22-25: DIST_SCALE = 1, light = min(v_light, 2 v_light - dist_term)
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         // a run of sky (sky.frag:12-26): the colour depends on the pixel and the pose only.  ndc_tab holds
         // p / (size / 2) - 1 for every column and row of the frame (computed once per batch with the same two
         // operations), the record carries v_r.y and 4 v_r.x / 3.14159265358; the row part is evaluated once per run.
-        const DeviceLevelView &lv = fc->lv;
+        const LevelSlice &lv = fc->lv.slices[pc.level];  // the sky of this pose's level
         const float *ndc_tab = fc->ndc_tab;
         const float ushift = __uint_as_float(r2.w), vr1 = __uint_as_float(r2.z), band = lv.sky_band;
         float uvy = (-ndc_tab[(uint32_t)width + row] + 1.0f) + vr1;
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         const float fy = uvy - floorf(uvy);
         int iy = (int)floorf(fy * (float)lv.sky_h);
         if (iy >= (int)lv.sky_h) iy = (int)lv.sky_h - 1;
-        const uint16_t *srow = lv.sky_tex + (size_t)iy * lv.sky_w;
+        const uint16_t *srow = fc->lv.sky_texels + ((size_t)lv.sky_base + (size_t)iy * lv.sky_w);
         uint32_t c[NPX];
 #pragma unroll
         for (int k = 0; k < NPX; k++) {
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
           const ShadeRec sh = prec[rec].s;
           const TexelAt t = texel_coords(sh, px, fmaf(sh.wp[1], py, sh.wp[2]), fmaf(sh.up[1], py, sh.up[2]),
                                          fmaf(sh.vp[1], py, sh.vp[2]));
-          pass = (load_texel(lv, sh, t.ix, t.iy) & 0x8000u) == 0u;
+          pass = (load_texel(lv.texels, sh, t.ix, t.iy) & 0x8000u) == 0u;
         }
         if (pass) {
           const uint32_t d24 = __float2uint_rz(fmaf(fminf(fmaxf(zw, 0.0f), 1.0f), 16777215.0f, 0.5f));

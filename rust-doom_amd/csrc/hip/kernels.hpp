@@ -27,12 +27,12 @@ rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelVie
                           TriRec *recs, uint32_t *visible, uint4 *sorted, uint32_t *counts, uint32_t *ghist, uint32_t cap,
                           uint32_t *mismatch_flag);  // set when the set-up kernel rejects a triangle the cull kernel kept
 size_t setup_histogram_bytes(uint32_t max_poses);  // scratch of the counting sort (per pose: one counter per depth bucket)
-// Kernel 1b: per-tile triangle lists (bin.hip).  false = the frame has too many tiles for the kernel's LDS counters:
-// nothing was launched and the caller must flag every pose as "bins incomplete"
-bool launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
-                uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
-                uint2 *hits, uint32_t *overflow,
-                bool want_split, bool *used_split);  // lists of more than LONG_LIST entries per quadrant, if the counters fit (bin.hip)
+// Kernel 1b: per-tile triangle lists (bin.hip).  *launched = false: the frame has too many tiles for the kernel's LDS counters --
+// nothing was launched and the caller must flag every pose as "bins incomplete".  A launch that FAILS is an error.
+rdoom_status launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
+                        uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
+                        uint2 *hits, uint32_t *overflow,
+                        bool want_split, bool *launched, bool *used_split);  // lists of more than LONG_LIST entries per quadrant, if the counters fit (bin.hip)
 // Kernel 2: tiled rasteriser -> visibility words (raster.hip)
 rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
                            const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,

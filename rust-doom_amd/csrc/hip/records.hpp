@@ -37,13 +37,14 @@ struct alignas(16) LevelTri {  // 96 bytes
 };
 static_assert(sizeof(LevelTri) == 96, "LevelTri layout");
 
-struct alignas(16) PoseConst {  // 464 bytes
+struct alignas(16) PoseConst {  // 480 bytes
   float pm[16];                 // projection * modelview (V1)
   float time, vr0, vr1, zk;     // zk: depth conditioning constant P[2][2] / P[2][3] (S5)
   uint8_t lights[256];
   float mv[16], proj[16];       // the two uniforms themselves: sprite.vert transforms in two steps (D1..D3)
+  uint32_t level, pad0, pad1, pad2;  // which level of the resident set this pose looks at (DeviceLevelView::slices; 0 for a single level)
 };
-static_assert(sizeof(PoseConst) == 464, "PoseConst layout");
+static_assert(sizeof(PoseConst) == 480, "PoseConst layout");
 
 // Per (pose, object) uniforms when objects move (doors, lifts): the reference sets u_modelview = view o model
 // transform for the draws of each object (engine/src/renderer.rs:120-132, game/src/level.rs:203-255).
@@ -113,22 +114,34 @@ struct alignas(16) Cluster {  // 32 bytes
 };
 static_assert(sizeof(Cluster) == 32, "Cluster layout");
 
-struct DeviceLevelView {
-  const LevelTri *tris;
-  uint32_t ntri;
-  const Cluster *clusters;
-  uint32_t n_clusters;
-  // one u16 texel store: the wall atlas (lo = palette index, bit 15 = transparent) followed, at element
-  // flat_base (a multiple of 1024), by the flat atlas promoted to u16 (hi byte 0: never transparent)
-  const uint16_t *texels;
-  uint32_t flat_base, decor_base;  // the decor (sprite) atlas follows the flats, also at a multiple of 1024
-  uint32_t flat_w, flat_h;
-  uint32_t wall_w, wall_h;
-  uint32_t decor_w, decor_h;
-  const uint16_t *sky_tex;
-  uint32_t sky_w, sky_h;
+// One level of the resident set (rdoom_levelset_create; rdoom_level_create = a set of one): its share of the set's triangle and
+// cluster arrays, where its atlases sit in the set's ONE u16 texel store, its sky.  The reference keeps one level loaded at a time
+// (game/src/level.rs:330-496 builds it, engine/src/renderer.rs:98-157 draws it); a pose batch over several levels -- BASELINE
+// config 4's share of one GPU -- would otherwise be one launch set per level.  A pose names its level (PoseConst::level); only the
+// cull / set-up kernels and the fragment stage's sky path look the slice up (scalar loads: a workgroup works on one pose), every
+// other reader finds what it needs in the pose's records (texel base, atlas masks).
+struct alignas(16) LevelSlice {  // 80 bytes
+  uint32_t first_cluster, n_clusters, first_tri, ntri;
+  // texel offsets in the set's store (multiples of 1024): the wall atlas (lo = palette index, bit 15 = transparent), the flat
+  // atlas promoted to u16 (hi byte 0: never transparent), the decor (sprite) atlas
+  uint32_t wall_base, flat_base, decor_base, sky_base;  // sky_base: offset of this level's sky texture in DeviceLevelView::sky_texels
+  uint32_t wall_w, wall_h, flat_w, flat_h;
+  uint32_t decor_w, decor_h, sky_w, sky_h;
   float sky_band;
-  const uint8_t *colormap;
+  uint32_t pad0, pad1, pad2;
+};
+static_assert(sizeof(LevelSlice) == 80, "LevelSlice layout");
+
+struct DeviceLevelView {
+  const LevelTri *tris;      // all levels' triangles, level after level; primitive id = index - slice.first_tri
+  const Cluster *clusters;   // Cluster::first indexes `tris`
+  const uint16_t *texels;    // one u16 texel store for every atlas of every level of the set
+  const uint16_t *sky_texels;
+  const uint8_t *colormap;   // COLORMAP of the IWAD (the levels of a set share it: rdoom_levelset_create checks)
+  const LevelSlice *slices;
+  uint32_t n_slices;
+  uint32_t max_clusters;     // the largest slice's cluster / triangle count: grid sizes and per-pose record strides
+  uint32_t max_ntri;
 };
 
 __device__ __forceinline__ float plane3(const float *p, float px, float py) {
@@ -227,8 +240,8 @@ __device__ __forceinline__ uint32_t texel_offset(uint32_t flags, uint32_t tex, i
   const uint32_t wm = tex & 0xFFFFu, hm = tex >> 16, lw = (flags >> 8) & 15u, base = (flags >> 16) << 10;
   return base + ((((uint32_t)iy & hm) << lw) | ((uint32_t)ix & wm));
 }
-__device__ __forceinline__ uint32_t load_texel(const DeviceLevelView &lv, const ShadeRec &s, int ix, int iy) {
-  return lv.texels[texel_offset(s.flags, s.tex, ix, iy)];
+__device__ __forceinline__ uint32_t load_texel(const uint16_t *__restrict__ texels, const ShadeRec &s, int ix, int iy) {
+  return texels[texel_offset(s.flags, s.tex, ix, iy)];
 }
 
 // x > 0 for a non-NaN binary32, as an integer test on the bits: a scalar compare when x is wave-uniform

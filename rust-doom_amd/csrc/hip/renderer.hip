@@ -37,12 +37,16 @@ static unsigned long long g_host_n;
 #define HT_MARK(i) do { } while (0)
 #endif
 
+// A resident SET of levels (rdoom_levelset_create); rdoom_level_create makes a set of one.
 struct rdoom_level {
   int device = 0;
   DeviceLevelView view{};
   void *d_clusters = nullptr;
-  void *d_tris = nullptr, *d_flat = nullptr, *d_wall = nullptr, *d_sky = nullptr, *d_cmap = nullptr;
-  uint32_t ntri = 0, n_objects = 1;
+  void *d_tris = nullptr, *d_texels = nullptr, *d_sky = nullptr, *d_cmap = nullptr, *d_slices = nullptr;
+  std::vector<LevelSlice> slices;      // host copy of the slice table
+  std::vector<uint32_t> slice_objects; // 1 + the largest object id each level draws
+  uint32_t ntri = 0;        // the LARGEST level's triangle count: a pose's records, visible list, sorted list have this stride
+  uint32_t n_objects = 1;   // 1 + the largest object id any level of the set draws
 };
 
 struct rdoom_batch {
@@ -143,16 +147,30 @@ rdoom_status rdoom_set_device(int32_t device) {
 
 void rdoom_level_destroy(rdoom_level *level) {
   if (!level) return;
-  for (void *p : {level->d_clusters, level->d_tris, level->d_flat, level->d_wall, level->d_sky, level->d_cmap})
+  for (void *p : {level->d_clusters, level->d_tris, level->d_texels, level->d_sky, level->d_cmap, level->d_slices})
     if (p) (void)hipFree(p);
   delete level;
 }
 
-static rdoom_status level_create_impl(const rdoom_level_desc *d, rdoom_level **out_level);
+// One level of a set, flattened on the host: what rdoom_levelset_create concatenates and uploads.
+namespace {
+struct HostLevel {
+  std::vector<LevelTri> tris;
+  std::vector<Cluster> clusters;     // Cluster::first relative to this level's first triangle
+  std::vector<uint16_t> texels;      // wall atlas, then (at multiples of 1024) the flat atlas promoted to u16, the decor atlas
+  size_t flat_base = 0, decor_base = 0;
+  std::vector<uint16_t> sky;
+  LevelSlice dims{};                 // the atlas / sky sizes (bases and ranges are filled in when the set is assembled)
+  uint32_t n_objects = 1;
+};
+}  // namespace
 
-rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_level) {
+static rdoom_status flatten_level(const rdoom_level_desc *d, HostLevel &out);
+static rdoom_status levelset_create_impl(const rdoom_level_desc *const *descs, uint32_t n_levels, rdoom_level **out_level);
+
+rdoom_status rdoom_levelset_create(const rdoom_level_desc *const *descs, uint32_t n_levels, rdoom_level **out_level) {
   try {  // std::vector / std::map below may throw: nothing unwinds across the C ABI
-    return level_create_impl(d, out_level);
+    return levelset_create_impl(descs, n_levels, out_level);
   } catch (const std::bad_alloc &) {
     return rdoom::fail(RDOOM_OOM, "out of host memory");
   } catch (const std::exception &e) {
@@ -160,9 +178,12 @@ rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_lev
   }
 }
 
-static rdoom_status level_create_impl(const rdoom_level_desc *d, rdoom_level **out_level) {
-  if (!d || !out_level) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
-  *out_level = nullptr;
+rdoom_status rdoom_level_create(const rdoom_level_desc *d, rdoom_level **out_level) {
+  return rdoom_levelset_create(&d, 1u, out_level);
+}
+
+static rdoom_status flatten_level(const rdoom_level_desc *d, HostLevel &out) {
+  if (!d) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   if (!d->colormap) return rdoom::fail(RDOOM_BAD_ARG, "colormap is null");
   if ((d->flat_atlas && !(d->flat_w && d->flat_h)) || (d->wall_atlas && !(d->wall_w && d->wall_h)) ||
       (d->decor_atlas && !(d->decor_w && d->decor_h)))
@@ -177,7 +198,7 @@ static rdoom_status level_create_impl(const rdoom_level_desc *d, rdoom_level **o
       d->decor_h > 32768)
     return rdoom::fail(RDOOM_BAD_ARG, "atlas larger than 32768 texels on a side");
   // flatten the draws into one primitive list in draw order (primitive id == position)
-  std::vector<LevelTri> tris;
+  std::vector<LevelTri> &tris = out.tris;
   uint32_t n_objects = 1;
   // Alpha-test classification of a wall texture (all its animation frames): bit 0 = a texel in the
   // one-texel ring AROUND the rectangle is transparent (the float mod of F2 can land there), bit 1 =
@@ -287,21 +308,9 @@ static rdoom_status level_create_impl(const rdoom_level_desc *d, rdoom_level **o
     }
   }
   if (tris.size() >= (1u << 24)) return rdoom::fail(RDOOM_BAD_LEVEL, "too many triangles (%zu)", tris.size());
-  rdoom_level *lv = new rdoom_level;
-  (void)hipGetDevice(&lv->device);
-  lv->ntri = (uint32_t)tris.size();
-  lv->n_objects = n_objects;
-  auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
-    if (bytes == 0 || !src) {
-      *dst = nullptr;
-      return hipSuccess;
-    }
-    hipError_t e = hipMalloc(dst, bytes);
-    if (e != hipSuccess) return e;
-    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-  };
+  out.n_objects = n_objects;
   // clusters for the set-up kernel's coarse cull: runs of at most CLUSTER_TRIS consecutive triangles of one object
-  std::vector<Cluster> clusters;
+  std::vector<Cluster> &clusters = out.clusters;
   for (size_t t = 0; t < tris.size();) {
     const uint32_t obj = tris[t].packed >> 20;
     const bool decor = ((tris[t].packed >> 16) & 3u) == RDOOM_KIND_DECOR;
@@ -321,48 +330,109 @@ static rdoom_status level_create_impl(const rdoom_level_desc *d, rdoom_level **o
     c.count_object = n | (obj << 8) | (decor ? 0x80000000u : 0u);
     clusters.push_back(c);
   }
-  hipError_t e = upload(&lv->d_tris, tris.data(), tris.size() * sizeof(LevelTri));
-  if (e == hipSuccess) e = upload(&lv->d_clusters, clusters.data(), clusters.size() * sizeof(Cluster));
-  // unified u16 texel store: wall atlas, then (at a multiple of 1024 elements) the flat atlas promoted to u16
+  // this level's u16 texels: wall atlas, then (at a multiple of 1024 elements) the flat atlas promoted to u16, the decor atlas
   const size_t wall_n = d->wall_atlas ? (size_t)d->wall_w * d->wall_h : 0;
   const size_t flat_n = d->flat_atlas ? (size_t)d->flat_w * d->flat_h : 0;
   const size_t decor_n = d->decor_atlas ? (size_t)d->decor_w * d->decor_h : 0;
-  const size_t flat_base = (wall_n + 1023) / 1024 * 1024;
-  const size_t decor_base = (flat_base + flat_n + 1023) / 1024 * 1024;
-  if (decor_base + decor_n >= ((size_t)1 << 26)) {
-    rdoom_level_destroy(lv);
-    return rdoom::fail(RDOOM_BAD_LEVEL, "atlases too large (%zu texels)", decor_base + decor_n);
+  out.flat_base = (wall_n + 1023) / 1024 * 1024;
+  out.decor_base = (out.flat_base + flat_n + 1023) / 1024 * 1024;
+  out.texels.assign((out.decor_base + decor_n + 1023) / 1024 * 1024, 0);
+  if (wall_n) std::memcpy(out.texels.data(), d->wall_atlas, wall_n * 2);
+  for (size_t i = 0; i < flat_n; i++) out.texels[out.flat_base + i] = d->flat_atlas[i];
+  if (decor_n) std::memcpy(out.texels.data() + out.decor_base, d->decor_atlas, decor_n * 2);
+  if (d->sky_texture && d->sky_w && d->sky_h) out.sky.assign(d->sky_texture, d->sky_texture + (size_t)d->sky_w * d->sky_h);
+  out.dims.wall_w = d->wall_w, out.dims.wall_h = d->wall_h;
+  out.dims.flat_w = d->flat_w, out.dims.flat_h = d->flat_h;
+  out.dims.decor_w = d->decor_atlas ? d->decor_w : 0, out.dims.decor_h = d->decor_atlas ? d->decor_h : 0;
+  out.dims.sky_w = out.sky.empty() ? 0 : d->sky_w, out.dims.sky_h = out.sky.empty() ? 0 : d->sky_h;
+  out.dims.sky_band = d->sky_tiled_band_size;
+  return RDOOM_OK;
+}
+
+static rdoom_status levelset_create_impl(const rdoom_level_desc *const *descs, uint32_t n_levels, rdoom_level **out_level) {
+  if (!descs || !out_level) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out_level = nullptr;
+  if (n_levels == 0 || n_levels > 4096u) return rdoom::fail(RDOOM_BAD_ARG, "n_levels %u outside 1..4096", n_levels);
+  std::vector<HostLevel> host(n_levels);
+  for (uint32_t k = 0; k < n_levels; k++) {
+    if (!descs[k]) return rdoom::fail(RDOOM_BAD_ARG, "level %u: null descriptor", k);
+    if (rdoom_status rs = flatten_level(descs[k], host[k])) return rs;
+    // the fragment kernel stages ONE COLORMAP in LDS per workgroup: the levels of a set come from one IWAD
+    // (build_palette_texture reads the archive's COLORMAP lump, wad/src/tex.rs:137-166)
+    if (k && std::memcmp(descs[k]->colormap, descs[0]->colormap, 32 * 256) != 0)
+      return rdoom::fail(RDOOM_BAD_ARG, "level %u: its COLORMAP differs from level 0's (the levels of a set share one)", k);
   }
-  std::vector<uint16_t> texels(decor_base + decor_n + 1, 0);  // never empty: masked-off lanes read element 0
-  if (wall_n) std::memcpy(texels.data(), d->wall_atlas, wall_n * 2);
-  for (size_t i = 0; i < flat_n; i++) texels[flat_base + i] = d->flat_atlas[i];
-  if (decor_n) std::memcpy(texels.data() + decor_base, d->decor_atlas, decor_n * 2);
-  if (e == hipSuccess) e = upload(&lv->d_wall, texels.data(), texels.size() * 2);
-  if (e == hipSuccess) e = upload(&lv->d_sky, d->sky_texture, (size_t)d->sky_w * d->sky_h * 2);
-  if (e == hipSuccess) e = upload(&lv->d_cmap, d->colormap, 32 * 256);
+  rdoom_level *lv = new rdoom_level;
+  (void)hipGetDevice(&lv->device);
+  // the set's arrays: triangles, clusters, texels, skies, level after level
+  std::vector<LevelTri> tris;
+  std::vector<Cluster> clusters;
+  std::vector<uint16_t> texels, sky;
+  lv->slices.resize(n_levels);
+  uint32_t max_clusters = 0;
+  for (uint32_t k = 0; k < n_levels; k++) {
+    HostLevel &h = host[k];
+    LevelSlice &sl = lv->slices[k];
+    sl = h.dims;
+    sl.first_tri = (uint32_t)tris.size(), sl.ntri = (uint32_t)h.tris.size();
+    sl.first_cluster = (uint32_t)clusters.size(), sl.n_clusters = (uint32_t)h.clusters.size();
+    sl.wall_base = (uint32_t)texels.size();
+    sl.flat_base = (uint32_t)(texels.size() + h.flat_base), sl.decor_base = (uint32_t)(texels.size() + h.decor_base);
+    sl.sky_base = (uint32_t)sky.size();
+    for (Cluster c : h.clusters) {
+      c.first += sl.first_tri;
+      clusters.push_back(c);
+    }
+    tris.insert(tris.end(), h.tris.begin(), h.tris.end());
+    texels.insert(texels.end(), h.texels.begin(), h.texels.end());
+    sky.insert(sky.end(), h.sky.begin(), h.sky.end());
+    lv->ntri = std::max(lv->ntri, sl.ntri);
+    lv->n_objects = std::max(lv->n_objects, h.n_objects);
+    lv->slice_objects.push_back(h.n_objects);
+    max_clusters = std::max(max_clusters, sl.n_clusters);
+    h = HostLevel{};  // (released: a set of many levels would otherwise hold every atlas twice)
+  }
+  // a record addresses the store with (base >> 10) in 16 bits (ShadeRec::flags), a cluster index fits 32 bits
+  if (texels.size() >= ((size_t)1 << 26)) {
+    const size_t n = texels.size();
+    rdoom_level_destroy(lv);
+    return rdoom::fail(RDOOM_BAD_LEVEL, "atlases too large (%zu texels in the set; at most 2^26)", n);
+  }
+  if (tris.size() >= ((size_t)1 << 31)) {
+    rdoom_level_destroy(lv);
+    return rdoom::fail(RDOOM_BAD_LEVEL, "too many triangles in the set");
+  }
+  texels.push_back(0);  // never empty; the fragment kernel's 32-bit load at the last texel's 2-byte-aligned address reads one past it
+  texels.push_back(0);
+  auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+    if (bytes == 0 || !src) {
+      *dst = nullptr;
+      return hipSuccess;
+    }
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  hipError_t e = upload(&lv->d_tris, tris.data(), tris.size() * sizeof(LevelTri));
+  if (e == hipSuccess) e = upload(&lv->d_clusters, clusters.data(), clusters.size() * sizeof(Cluster));
+  if (e == hipSuccess) e = upload(&lv->d_texels, texels.data(), texels.size() * 2);
+  if (e == hipSuccess) e = upload(&lv->d_sky, sky.data(), sky.size() * 2);
+  if (e == hipSuccess) e = upload(&lv->d_cmap, descs[0]->colormap, 32 * 256);
+  if (e == hipSuccess) e = upload(&lv->d_slices, lv->slices.data(), lv->slices.size() * sizeof(LevelSlice));
   if (e != hipSuccess) {
     rdoom_level_destroy(lv);
     return rdoom::fail(e == hipErrorOutOfMemory ? RDOOM_OOM : RDOOM_HIP_ERROR, "level upload failed: %s",
                        hipGetErrorString(e));
   }
   lv->view.tris = (const LevelTri *)lv->d_tris;
-  lv->view.ntri = lv->ntri;
   lv->view.clusters = (const Cluster *)lv->d_clusters;
-  lv->view.n_clusters = (uint32_t)clusters.size();
-  lv->view.texels = (const uint16_t *)lv->d_wall;
-  lv->view.flat_base = (uint32_t)flat_base;
-  lv->view.decor_base = (uint32_t)decor_base;
-  lv->view.decor_w = d->decor_atlas ? d->decor_w : 0;
-  lv->view.decor_h = d->decor_atlas ? d->decor_h : 0;
-  lv->view.flat_w = d->flat_w;
-  lv->view.flat_h = d->flat_h;
-  lv->view.wall_w = d->wall_w;
-  lv->view.wall_h = d->wall_h;
-  lv->view.sky_tex = (const uint16_t *)lv->d_sky;
-  lv->view.sky_w = lv->d_sky ? d->sky_w : 0;
-  lv->view.sky_h = lv->d_sky ? d->sky_h : 0;
-  lv->view.sky_band = d->sky_tiled_band_size;
+  lv->view.texels = (const uint16_t *)lv->d_texels;
+  lv->view.sky_texels = (const uint16_t *)lv->d_sky;
   lv->view.colormap = (const uint8_t *)lv->d_cmap;
+  lv->view.slices = (const LevelSlice *)lv->d_slices;
+  lv->view.n_slices = n_levels;
+  lv->view.max_clusters = max_clusters;
+  lv->view.max_ntri = lv->ntri;
   *out_level = lv;
   return RDOOM_OK;
 }
@@ -429,7 +499,10 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   // sized generously -- never beyond what the level could ever need: every triangle in every quadrant of every tile
   // (the floor scales with the frame: 256 entries per tile, at least 16 384 -- 131 072 for the 510 tiles of 1080p as before,
   // 16 384 instead of 131 072 for the 20 tiles of 320 x 200, whose 8 192-pose batches had 12.9 GB of binning scratch)
-  b->entry_cap = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(std::max<uint32_t>(16384u, 256u * b->n_tiles), 64u * b->n_tiles),
+  // -- and with the level: a split list stores an entry once per quadrant it touches, so a large level at a small frame (the 10x
+  // level, 36 k triangles, at 320 x 200) needs more than 16 384 per pose or every such pose silently takes the overflow path)
+  const uint64_t floor_entries = std::max<uint64_t>(std::max<uint64_t>(16384u, 256u * (uint64_t)b->n_tiles), std::min<uint64_t>(2u * (uint64_t)b->cap, 1u << 20));
+  b->entry_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(floor_entries, 64u * (uint64_t)b->n_tiles),
                                               (uint64_t)b->cap * b->n_tiles * 4u + 8u * (uint64_t)b->n_tiles);
   b->entry_cap = (b->entry_cap + 3u) & ~3u;
   if (dbg.entry_cap > 0) b->entry_cap = (uint32_t)dbg.entry_cap;  // tests: force that fallback
@@ -481,12 +554,31 @@ static void mat_mul_v1(const float *P, const float *M, float *pm) {  // V1: PM =
                       P[3 * 4 + r] * M[c * 4 + 3];
 }
 
+// Records ev_done on every way out of render_impl once kernels may have been queued: rdoom_batch_finish and the read functions
+// wait for THAT event, and a render that failed half-way must not leave them waiting for the render before it while its
+// own kernels still write the batch's scratch.
+namespace {
+struct DoneGuard {
+  rdoom_batch *b;
+  hipStream_t st;
+  bool armed = false;
+  ~DoneGuard() {
+    if (armed) (void)hipEventRecord(b->ev_done, st);
+  }
+};
+}  // namespace
+
 static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const uint8_t *lights, uint32_t lights_stride,
                                 uint32_t n, uint32_t kinds_mask, hipStream_t st, rdoom_timings *tm,
-                                const float *object_modelviews = nullptr, uint32_t n_objects = 0, bool profiled = false) {
+                                const float *object_modelviews = nullptr, uint32_t n_objects = 0, bool profiled = false,
+                                const uint32_t *level_of_pose = nullptr) {
   if (!b || !poses || !lights) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
   if (n == 0 || n > b->max_poses) return rdoom::fail(RDOOM_BAD_ARG, "n_poses %u outside 1..%u", n, b->max_poses);
   const rdoom_level *lv = b->level;
+  if (level_of_pose)
+    for (uint32_t p = 0; p < n; p++)
+      if (level_of_pose[p] >= lv->view.n_slices)
+        return rdoom::fail(RDOOM_BAD_ARG, "pose %u names level %u of a set of %u", p, level_of_pose[p], lv->view.n_slices);
   HIP_TRY(hipSetDevice(lv->device));  // level, scratch and kernels on one device (several GPUs driven from one process)
   if (object_modelviews && n_objects < lv->n_objects)
     return rdoom::fail(RDOOM_BAD_ARG, "n_objects %u but the level draws objects 0..%u", n_objects, lv->n_objects - 1);
@@ -524,6 +616,8 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     pc.vr1 = pc.pm[9] / pc.pm[11];
     pc.zk = pc.proj[11] != 0.0f ? pc.proj[10] / pc.proj[11] : 0.0f;  // S5: Z - zk * W is small for a perspective matrix
     std::memcpy(pc.lights, lights + (size_t)p * lights_stride, 256);
+    pc.level = level_of_pose ? level_of_pose[p] : 0u;
+    pc.pad0 = pc.pad1 = pc.pad2 = 0u;
   }
   b->last_n = n;
   HT_MARK(1);
@@ -536,6 +630,8 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   }
   const bool marks = tm || profiled;
   if (marks) HIP_TRY(hipEventRecord(ev[0], st));
+  DoneGuard done{b, st};
+  done.armed = true;  // from here on work of this render may be queued: whatever happens, ev_done is recorded after it
   HIP_TRY(hipMemcpyAsync(b->d_poses, h_poses, sizeof(PoseConst) * n, hipMemcpyHostToDevice, st));
   if (object_modelviews)
     HIP_TRY(hipMemcpyAsync(b->d_objects, b->h_objects[sg], sizeof(ObjectConst) * (size_t)n * lv->n_objects,
@@ -553,9 +649,11 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   HT_MARK(3);
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   bool split_lists = false;  // long tile lists stored per quadrant this render (binning kernel and rasteriser must agree)
-  const bool bins = lv->ntri && !rdoom::debug_options().no_bins &&
-                    launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
-                               b->entry_cap, b->d_hits, b->d_overflow, !rdoom::debug_options().no_split, &split_lists);
+  bool bins = false;
+  if (lv->ntri && !rdoom::debug_options().no_bins)
+    if (rdoom_status rs = launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
+                                     b->entry_cap, b->d_hits, b->d_overflow, !rdoom::debug_options().no_split, &bins, &split_lists))
+      return rs;
   if (!bins) {
     HIP_TRY(hipMemsetAsync(b->d_overflow, 0xFF, sizeof(uint32_t) * n, st));
   }
@@ -579,6 +677,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
     return rs;
   HIP_TRY(hipGetLastError());
   HT_MARK(6);
+  done.armed = false;
   HIP_TRY(hipEventRecord(b->ev_done, st));
   HT_MARK(7);
 #ifdef RDOOM_HOST_TIMERS
@@ -660,6 +759,21 @@ rdoom_status rdoom_batch_render_objects(rdoom_batch *batch, const rdoom_pose *po
   if (!object_modelviews) return rdoom::fail(RDOOM_BAD_ARG, "object_modelviews is null");
   return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, nullptr,
                      object_modelviews, n_objects);
+}
+
+rdoom_status rdoom_batch_render_levels(rdoom_batch *batch, const rdoom_pose *poses, const uint32_t *level_of_pose, const uint8_t *lights,
+                                       uint32_t lights_stride, uint32_t n_poses, uint32_t kinds_mask, void *stream,
+                                       const float *object_modelviews, uint32_t n_objects, uint32_t flags) {
+  if (!level_of_pose) return rdoom::fail(RDOOM_BAD_ARG, "level_of_pose is null");
+  if (flags & ~(uint32_t)RDOOM_RENDER_PROFILED) return rdoom::fail(RDOOM_BAD_ARG, "unknown flags 0x%x", flags);
+  return render_impl(batch, poses, lights, lights_stride, n_poses, kinds_mask, (hipStream_t)stream, nullptr, object_modelviews,
+                     n_objects, (flags & RDOOM_RENDER_PROFILED) != 0u, level_of_pose);
+}
+
+rdoom_status rdoom_level_num_levels(const rdoom_level *level, uint32_t *out) {
+  if (!level || !out) return rdoom::fail(RDOOM_BAD_ARG, "null argument");
+  *out = level->view.n_slices;
+  return RDOOM_OK;
 }
 
 rdoom_status rdoom_level_num_objects(const rdoom_level *level, uint32_t *out) {

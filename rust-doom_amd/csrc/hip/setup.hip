@@ -67,7 +67,7 @@ __device__ __forceinline__ bool cluster_culled(const Cluster &c, const float *pm
   return left | right | below | above;
 }
 
-__device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const PoseConst &pc,
+__device__ __forceinline__ bool setup_triangle(const LevelSlice &lv, const PoseConst &pc,
                                                const ObjectConst *__restrict__ objs, uint32_t t, const LevelTri &tri,
                                                int width, int height, uint32_t kinds_mask, RasterRec &rr, ShadeRec &sr,
                                                float &wkey) {
@@ -191,7 +191,7 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
           rr.bb0 = (uint32_t)x0 | ((uint32_t)y0 << 16);
           rr.bb1 = (uint32_t)x1 | ((uint32_t)y1 << 16);
           const uint32_t masked = (tri.packed >> 18) & 3u;  // border, interior
-          rr.flags = (t & 0xFFFFFFu) | (tl << 24) | (kind << 27) | (masked << 29);
+          rr.flags = ((t - lv.first_tri) & 0xFFFFFFu) | (tl << 24) | (kind << 27) | (masked << 29);  // primitive id: position in ITS level's draw order
           rr.pad = 0;
           sr.atlas_u = au;
           sr.atlas_v = av;
@@ -203,7 +203,7 @@ __device__ __forceinline__ bool setup_triangle(const DeviceLevelView &lv, const 
           const bool is_flat = kind == RDOOM_KIND_FLAT, is_decor = kind == RDOOM_KIND_DECOR;
           const uint32_t aw = is_flat ? lv.flat_w : (is_decor ? lv.decor_w : lv.wall_w);
           const uint32_t ah = is_flat ? lv.flat_h : (is_decor ? lv.decor_h : lv.wall_h);
-          const uint32_t tbase = is_flat ? lv.flat_base : (is_decor ? lv.decor_base : 0u);
+          const uint32_t tbase = is_flat ? lv.flat_base : (is_decor ? lv.decor_base : lv.wall_base);
           const uint32_t lw = aw ? 31u - (uint32_t)__clz(aw) : 0u;
           auto packed_ok = [](float sz, bool p2) {
             return p2 ? (sz >= 0x1p-20f && sz <= 0x1p20f) : (sz >= 1.0f && sz <= 4096.0f && floorf(sz) == sz);
@@ -247,16 +247,17 @@ __global__ __launch_bounds__(256, RDOOM_CULL_OCC) void cull_kernel(DeviceLevelVi
   // workgroups per CU
   uint32_t *cand = reinterpret_cast<uint32_t *>(wstage[0]);
   static_assert(sizeof(uint32_t) * CULL_CHUNK <= sizeof(uint4) * 384, "cull_kernel: cand does not fit a wave's stage");
-  const uint32_t pose = blockIdx.y, group = blockIdx.x;
+  const uint32_t pose = blockIdx.x / groups, group = blockIdx.x - pose * groups;  // (one-dimensional grid: any number of poses)
   const PoseConst &pc = poses[pose];
+  const LevelSlice &ls = lv.slices[pc.level];  // (uniform: scalar loads)
   const ObjectConst *objs = objects ? objects + (size_t)pose * n_objects : nullptr;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   uint32_t *pvisible = visible + (size_t)pose * cap;  // the pose's visible triangles, in arrival order
   uint32_t *phist = ghist + (size_t)pose * SORT_BUCKETS;
   for (uint32_t i = tid; i < SORT_BUCKETS; i += 256) hist[i] = 0;
   // my share of the level's clusters
-  const uint32_t c_begin = (uint32_t)(((uint64_t)lv.n_clusters * group) / groups),
-                 c_end = (uint32_t)(((uint64_t)lv.n_clusters * (group + 1u)) / groups);
+  const uint32_t c_begin = ls.first_cluster + (uint32_t)(((uint64_t)ls.n_clusters * group) / groups),
+                 c_end = ls.first_cluster + (uint32_t)(((uint64_t)ls.n_clusters * (group + 1u)) / groups);
   // Phase 0, coarse cull: one lane per cluster, survivors listed in order
   const bool listed = c_end - c_begin <= CLUSTER_LIST;
   uint32_t n_live = c_end - c_begin;  // uniform
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256, RDOOM_CULL_OCC) void cull_kernel(DeviceLevelVi
         RasterRec rr;
         ShadeRec sr;
         float wkey;
-        if (setup_triangle(lv, pc, objs, tri_of[j], tri, width, height, kinds_mask, rr, sr, wkey)) vis4 |= 1u << j;
+        if (setup_triangle(ls, pc, objs, tri_of[j], tri, width, height, kinds_mask, rr, sr, wkey)) vis4 |= 1u << j;
         bucket_of[j] = depth_bucket(wkey);
       }
     }
@@ -395,9 +396,10 @@ __global__ __launch_bounds__(256, RDOOM_SETUP_OCC) void setup_kernel(DeviceLevel
                                                     const uint32_t *__restrict__ visible, TriRec *__restrict__ recs,
                                                     uint4 *__restrict__ sorted, const uint32_t *__restrict__ counts,
                                                     uint32_t *__restrict__ ghist, uint32_t cap,
-                                                    uint32_t *__restrict__ mismatch_flag) {
-  const uint32_t pose = blockIdx.y, n = counts[pose];
+                                                    uint32_t *__restrict__ mismatch_flag, uint32_t place_groups) {
+  const uint32_t pose = blockIdx.x / place_groups, pgroup = blockIdx.x - pose * place_groups, n = counts[pose];
   const PoseConst &pc = poses[pose];
+  const LevelSlice &ls = lv.slices[pc.level];
   const ObjectConst *objs = objects ? objects + (size_t)pose * n_objects : nullptr;
   const uint32_t *pvisible = visible + (size_t)pose * cap;
   TriRec *prec = recs + (size_t)pose * cap;
@@ -407,10 +409,10 @@ __global__ __launch_bounds__(256, RDOOM_SETUP_OCC) void setup_kernel(DeviceLevel
   // occurs claims its run with ONE global atomic (a returning global atomic per record serialises on the few buckets a
   // pose's triangles crowd into)
   __shared__ uint32_t lcount[SORT_BUCKETS], lbase[SORT_BUCKETS];
-  if (blockIdx.x * 256u >= n) return;  // uniform: nothing for this workgroup
+  if (pgroup * 256u >= n) return;  // uniform: nothing for this workgroup
   for (uint32_t i = threadIdx.x; i < SORT_BUCKETS; i += 256u) lcount[i] = 0;
   __syncthreads();
-  for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {  // uniform per workgroup
+  for (uint32_t i0 = pgroup * 256u; i0 < n; i0 += place_groups * 256u) {  // uniform per workgroup
     const uint32_t i = i0 + threadIdx.x;
     const bool valid = i < n;
     TriRec rec;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(256, RDOOM_SETUP_OCC) void setup_kernel(DeviceLevel
       // visible: the cull kernel said so, with the same operations (-ffp-contract=off, every deciding product an explicit
       // fmaf), and counted this bucket.  Should a build ever break that, the histogram's runs no longer add up: flagged,
       // and reported by rdoom_batch_finish / the read functions instead of drawing from overwritten records.
-      if (!setup_triangle(lv, pc, objs, t, tri, width, height, kinds_mask, rec.r, rec.s, wkey)) *mismatch_flag = 1u;
+      if (!setup_triangle(ls, pc, objs, t, tri, width, height, kinds_mask, rec.r, rec.s, wkey)) *mismatch_flag = 1u;
       bucket = depth_bucket(wkey);
 #ifndef RDOOM_NO_EMPTY_CULL
       // A triangle whose bbox holds at most 3 x 3 pixel centres and covers none of them (the rasteriser's own edge
@@ -478,13 +480,18 @@ rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelVie
                           uint32_t *mismatch_flag) {
   // (counts and ghist arrive zeroed: the caller clears them together with its other per-render words in one fill)
   // several workgroups per pose on large levels (each takes a share of the clusters): one would walk them serially
-  const uint32_t groups = std::min<uint32_t>(std::max<uint32_t>(lv.n_clusters / 96u, 1u), 16u);
-  hipLaunchKernelGGL(cull_kernel, dim3(groups, n_poses), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,
+  // (of a set of levels: by the largest; a smaller level's workgroups take shorter shares)
+  const uint32_t groups = std::min<uint32_t>(std::max<uint32_t>(lv.max_clusters / 96u, 1u), 16u);
+  (void)hipGetLastError();  // (a stale error of an earlier, unrelated call must not be blamed on these launches)
+  hipLaunchKernelGGL(cull_kernel, dim3(n_poses * groups), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,
                      kinds_mask, visible, counts, ghist, cap, groups);
   hipLaunchKernelGGL(sort_scan_kernel, dim3(n_poses), dim3(256), 0, st, ghist);
   const uint32_t place_groups = std::min<uint32_t>((cap + 1023u) / 1024u, 16u);  // about a fifth of a level is visible: one or two chunks of 256 records each
-  hipLaunchKernelGGL(setup_kernel, dim3(place_groups, n_poses), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,
-                     kinds_mask, visible, recs, sorted, counts, ghist, cap, mismatch_flag);
+  hipLaunchKernelGGL(setup_kernel, dim3(n_poses * place_groups), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,
+                     kinds_mask, visible, recs, sorted, counts, ghist, cap, mismatch_flag, place_groups);
+  // a launch that failed (an invalid configuration) must not go unreported: the binning kernel would build its lists from stale
+  // records and counts and the render would still return RDOOM_OK
+  HIP_TRY(hipGetLastError());
   return RDOOM_OK;
 }
 

@@ -27,17 +27,23 @@ def strip_comments(text):
 
 
 def rust_type(ctype, names):
-    """`const T *`, `T **`, `T` -> Rust; names = struct / opaque types the header defines"""
-    t = ctype.strip()
-    stars = t.count('*')
-    t = t.replace('*', ' ').strip()
-    const = t.startswith('const ')
-    base = t[6:].strip() if const else t
+    """`const T *`, `T **`, `const T *const *`, `T` -> Rust; names = struct / opaque types the header defines"""
+    t = ' '.join(ctype.replace('*', ' * ').split())
+    toks = t.split(' ')
+    const = toks[0] == 'const'
+    base = toks[1] if const else toks[0]
     if base not in SCALARS and base not in names:
         raise SystemExit('gen_rust_binding: unknown C type %r' % ctype)
     r = SCALARS.get(base, base)
-    for i in range(stars):
-        r = ('*const ' if (const and i == 0) else '*mut ') + r
+    # every `*` makes a pointer to what stands left of it; a `const` right after a `*` qualifies THAT pointer, i.e. what the
+    # next `*` points at
+    pointee_const = const
+    for i, tok in enumerate(toks[2 if const else 1:], start=2 if const else 1):
+        if tok == '*':
+            r = ('*const ' if pointee_const else '*mut ') + r
+            pointee_const = i + 1 < len(toks) and toks[i + 1] == 'const'
+        elif tok != 'const':
+            raise SystemExit('gen_rust_binding: unknown C type %r' % ctype)
     return r
 
 
