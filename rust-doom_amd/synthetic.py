@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 WAD_PATH = os.path.join(GOLDEN, 'synth.wad')
 BIG_WAD_PATH = os.path.join(GOLDEN, 'synth_big.wad')
+RICH_WAD_PATH = os.path.join(GOLDEN, 'synth_rich.wad')
 META_PATH = os.path.join(ROOT, 'assets', 'meta', 'synth.toml')   # metadata in the reference's schema (assets/meta/doom.toml)
 
 
@@ -37,6 +38,15 @@ def ensure_big_wad():
     if not os.path.exists(BIG_WAD_PATH):
         _generate(BIG_WAD_PATH, specs=[('E1M1', ('gen', 424242, 128, 90))])
     return BIG_WAD_PATH
+
+
+def ensure_rich_wad():
+    """A third IWAD with ONE level: E1M1's geometry (same generator seed), but every linedef side with a wall texture of its own out
+    of 320 and every sector its own flats out of 192 -- a wall atlas of 2048 x 2048 and more, a texel store several times one
+    XCD's L2 (tools/mkwad.py build_wad(rich=True)).  The nine default levels keep theirs at 1.1 MB, which a real IWAD does not."""
+    if not os.path.exists(RICH_WAD_PATH):
+        _generate(RICH_WAD_PATH, specs=[('E1M1', ('gen', 1993 * 7 + 1, 52, 14))], rich=True)
+    return RICH_WAD_PATH
 
 
 def wad_digest():

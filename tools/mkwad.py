@@ -287,6 +287,61 @@ def make_graphics(rng, shapes=False):
     return patches, pnames, textures, flats, sprites, textures2
 
 
+def rich_graphics(seed, n_walls=320, n_flats=192):
+    """The texture-rich stand-in (build_wad(rich=True)): `n_walls` wall textures of the sizes real IWADs use, each with a patch
+    of its own (every fourth one composed of two), and `n_flats` flats -- so that a level whose every linedef and sector picks
+    its own ends up with a wall atlas of 2048 x 2048 and more (wad/src/tex.rs:168-271) and a flat atlas of 1024 x 1024
+    (tex.rs:273-333): a texel store several times one XCD's 4 MiB of L2, where the nine default levels keep theirs at 1.1 MB.
+    Patterns as tex_pattern's, with the noise from an integer hash of (texture, x, y) (numpy; a Python-level xorshift per texel
+    would take minutes).  Returns (patches, textures as (name, w, h, [(ox, oy, patch name)]), flats)."""
+    sizes = [(64, 128), (128, 128), (128, 128), (256, 128), (64, 128), (128, 128), (64, 72), (256, 128), (128, 64), (64, 64), (24, 128), (128, 96)]
+    kinds = ['brick', 'panel', 'stripe', 'rock', 'grad', 'door', 'checker']
+
+    def pattern(kind, w, h, ramp, salt):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.uint32)
+        v = (xx * np.uint32(0x9E3779B1)) ^ (yy * np.uint32(0x85EBCA77)) ^ np.uint32((salt * 0xC2B2AE3D + seed) & 0xFFFFFFFF)
+        v ^= v >> np.uint32(15)
+        v = v * np.uint32(0x2C1B3C6D)
+        v ^= v >> np.uint32(12)
+        noise = (v & np.uint32(3)).astype(np.int64)
+        xx, yy = xx.astype(np.int64), yy.astype(np.int64)
+        k = salt % 7 + 1
+        if kind == 'brick':
+            row = yy // 16
+            bx = (xx + (row % 2) * 16) % 32
+            shade = 4 + noise + np.where((yy % 16 == 0) | (bx == 0), 6, 0)
+        elif kind == 'panel':
+            shade = 3 + noise + np.where((xx % 32 < 2) | (yy % 64 < 2), 7, 0) + (yy * 3 // h)
+        elif kind == 'stripe':
+            shade = 2 + ((xx // (4 * k) + yy // 8) % 2) * 5 + noise
+        elif kind == 'rock':
+            shade = 3 + noise * 2 + ((xx * (5 + k) + yy * 13) % 5)
+        elif kind == 'grad':
+            shade = (xx * 12 // max(w, 1)) + (yy * 3 // max(h, 1)) + (noise >> 1)
+        elif kind == 'door':
+            shade = 4 + noise + np.where((xx < 4) | (xx >= w - 4) | (yy < 4) | (yy % 24 == 0), 6, 0)
+        else:
+            shade = 2 + ((xx // (8 + 2 * k) + yy // 16) % 2) * 8 + (noise >> 1)
+        return (ramp * 16 + np.clip(shade, 0, 15)).astype(np.int16)
+
+    patches, textures, flats = {}, [], {}
+    for i in range(n_walls):
+        w, h = sizes[i % len(sizes)]
+        name, pname = 'RW%03d' % i, 'RP%03d' % i
+        patches[pname] = pattern(kinds[i % len(kinds)], w, h, 1 + i % 15, i)
+        prefs = [(0, 0, pname)]
+        if i % 4 == 3 and i >= 4:   # a second patch over the first, from an earlier texture (clipped where it hangs over)
+            prefs.append((w // 4, h // 4, 'RP%03d' % (i - 4)))
+        textures.append((name, w, h, prefs))
+    for i in range(n_flats):
+        flats['RF%03d' % i] = pattern(kinds[(i * 3) % len(kinds)], 64, 64, 1 + (i * 7) % 15, 1000 + i).astype(np.uint8)
+    return patches, textures, flats
+
+
+# when build_wad(rich=True) is at work: every linedef side picks ITS OWN wall texture from this list (None: the sector's)
+RICH_WALLS = None
+
+
 # --------------------------------------------------------------------------------------
 # level authoring on a cell grid
 # --------------------------------------------------------------------------------------
@@ -695,7 +750,7 @@ def build_lines(L, rng):
             flags = 1
             if rng.chance(0.2):
                 flags |= 0x10  # lower unpegged one-sided
-            mid = R.wall
+            mid = rng.choice(RICH_WALLS) if RICH_WALLS else R.wall
             if rs in L.scroll_sectors and rng.chance(0.5):
                 special = 48
             if rng.chance(0.02):
@@ -730,6 +785,8 @@ def build_lines(L, rng):
                     lo if back.floor > front.floor or back.kind == 'lift' else '-')
         ur, lr = side_tex(R, Ls)
         ul, ll = side_tex(Ls, R)
+        if RICH_WALLS:   # every upper / lower piece its own texture
+            ur, lr, ul, ll = [rng.choice(RICH_WALLS) if t != '-' else t for t in (ur, lr, ul, ll)]
         if R.kind == 'door':
             mid_r = '-'
         sidedefs.append((xo, yo, ur, lr, mid_r, rs))
@@ -948,23 +1005,51 @@ def texture_lump(textures):
     return struct.pack('<I', len(textures)) + b''.join(struct.pack('<I', o) for o in offs) + body
 
 
-def build_wad(seed=1993, verbose=False, specs=None, shapes=False):
+def build_wad(seed=1993, verbose=False, specs=None, shapes=False, rich=False):
     """specs (optional): list of (level name, ('gen', seed, grid, rooms) | ('kat',)) replacing the nine default levels.
     shapes: the lump shapes of real IWADs the default file lacks -- TEXTURE2, duplicated lump names (the LAST one is the
     one a name finds: wad/src/archive.rs:85), sprite lumps with paired rotations, textures of many overlapping patches;
-    the levels then use the extra textures and things (the default IWAD, its levels and digests are unchanged)."""
-    global WALLS, DECOR_TYPES
+    the levels then use the extra textures and things (the default IWAD, its levels and digests are unchanged).
+    rich: the texture-rich stand-in (rich_graphics): 320 more wall textures and 192 more flats; every linedef side picks its own
+    wall texture, every sector its own floor and ceiling flat."""
+    global WALLS, DECOR_TYPES, FLOORS, CEILS, RICH_WALLS
     rng = Rng(seed)
     pals = make_playpal()
     cmaps = make_colormap(pals[0])
     patches, pnames, textures, flats, sprites, textures2 = make_graphics(rng, shapes)
+    rich_names = None
+    if rich:
+        rp, rt, rf = rich_graphics(seed)
+        missing = pnames.pop()          # ('MISSING1' stays the last name: it has no lump)
+        patches.update(rp)
+        pnames += list(rp.keys()) + [missing]
+        textures = [(n, w, h, [(ox, oy, pnames.index(pn) if isinstance(pn, str) else (pn if pn < len(pnames) - 1 - len(rp) else len(pnames) - 1)) for ox, oy, pn in prefs])
+                    for (n, w, h, prefs) in textures + rt]
+        flats.update(rf)
+        rich_names = ([t[0] for t in rt], list(rf.keys()))
     lumps = [('PLAYPAL', b''.join(p.tobytes() for p in pals)),
              ('COLORMAP', b''.join(c.tobytes() for c in cmaps))]
     lumps.append(('TEXTURE1', texture_lump(textures)))
     if textures2:
         lumps.append(('TEXTURE2', texture_lump(textures2)))
     lumps.append(('PNAMES', struct.pack('<I', len(pnames)) + b''.join(name8(n) for n in pnames)))
-    saved = WALLS, DECOR_TYPES
+    saved = WALLS, DECOR_TYPES, FLOORS, CEILS
+    if rich:
+        # sectors take their flats in turn (gen_level draws rng.choice(FLOORS) / rng.choice(CEILS): a list per call would change
+        # the number of draws and with it the geometry -- a sequence object whose indexing ignores the draw keeps E1M1's shape)
+        class InTurn(list):
+            def __init__(self, names):
+                super().__init__(names)
+                self.at = 0
+
+            def __getitem__(self, _i):
+                v = list.__getitem__(self, self.at % len(self))
+                self.at += 1
+                return v
+        half = len(rich_names[1]) // 2
+        FLOORS, CEILS = InTurn(rich_names[1][:half]), InTurn(rich_names[1][half:])
+        WALLS = InTurn(rich_names[0])
+        RICH_WALLS = rich_names[0]
     if shapes:
         WALLS = WALLS + ['OVERLAP3', 'GRATEMIX', 'T2ONLY']
         DECOR_TYPES = DECOR_TYPES + [3004, 3004]
@@ -981,7 +1066,8 @@ def build_wad(seed=1993, verbose=False, specs=None, shapes=False):
             lumps.append((name, b''))
             lumps.extend(ll)
     finally:
-        WALLS, DECOR_TYPES = saved
+        WALLS, DECOR_TYPES, FLOORS, CEILS = saved
+        RICH_WALLS = None
     lumps.append(('P_START', b''))
     for n, pix in patches.items():
         if shapes and n in ('WALL02_1', 'STEP1'):   # a decoy under the same name FIRST: the name must find the later lump
