@@ -69,7 +69,6 @@ __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *tmp) {
 #endif
 template <int BIN_THREADS, int BIN_LOG2>  // threads per workgroup = triangles staged per round (one per thread)
 __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const TriRec *__restrict__ recs,
-                                                          const uint4 *__restrict__ sorted,
                                                           const uint32_t *__restrict__ counts, uint32_t cap,
                                                           int tiles_x, int tiles_y, uint2 *__restrict__ tile_hdr,
                                                           uint32_t *__restrict__ entries, uint32_t entry_cap,
@@ -96,7 +95,6 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
   unsigned long long *qc = bin_dyn;
   uint32_t *tile_cnt = reinterpret_cast<uint32_t *>(bin_dyn + (split ? T : 0u));
   const TriRec *prec = recs + (size_t)pose * cap;
-  const uint4 *psorted = sorted + (size_t)pose * cap;
   uint2 *hdr = tile_hdr + (size_t)pose * T;
   uint32_t *pent = entries + (size_t)pose * entry_cap;
   uint2 *phits = hits + (size_t)pose * entry_cap;  // (entry, tile) of every pair that passed: the fill pass only scatters
@@ -110,15 +108,30 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
     for (uint32_t cbase = 0; cbase < n; cbase += BIN_CHUNK) {
       const uint32_t cn = min(BIN_CHUNK, n - cbase);
       __syncthreads();  // previous round's readers of coef/pref are done (and the tile counters are zeroed)
+      // Staging, line by line: the first 64 bytes of a record (edges, depth plane, bbox) are four 16-byte words, and FOUR
+      // consecutive lanes read the four words of one record -- a wave's load instruction touches 16 half lines, each whole, where a
+      // lane reading its own record at the records' 128-byte stride touched 64 lines for 16 bytes each, three times over (round 6;
+      // the bbox used to come from a second array, `sorted`, which repeated what the record holds).  A wave stages the 64 records
+      // its own lanes will work on: no workgroup barrier between the staging and the reads below.
+      {
+        const uint32_t lane = (uint32_t)tid & 63u, w64 = (uint32_t)tid & ~63u, word = lane & 3u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+          const uint32_t r = w64 + (lane >> 2) + 16u * j;
+          if (r < cn) {
+            const uint4 v = reinterpret_cast<const uint4 *>(&prec[cbase + r])[word];
+            if (word < 3u)
+              coef[r][word] = v;
+            else
+              bbox[r] = make_uint2(v.x, v.y);  // (bb0, bb1, flags, pad)
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
       uint32_t nt = 0;
       if ((uint32_t)tid < cn) {
-        const uint4 ent = psorted[cbase + tid];  // (bb0, bb1, record index == cbase + tid, depth bucket)
-        const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[cbase + tid]);
-        const uint4 c0 = rp[0], c1 = rp[1], c2 = rp[2];
-        coef[tid][0] = c0;
-        coef[tid][1] = c1;
-        coef[tid][2] = c2;
-        bbox[tid] = make_uint2(ent.x, ent.y);
+        const uint4 c0 = coef[tid][0], c1 = coef[tid][1], c2 = coef[tid][2];
+        const uint2 ent = bbox[tid];
         int tx0 = (int)((ent.x & 0xFFFFu) >> 6), ty0 = (int)((ent.x >> 16) >> 6), tx1 = (int)((ent.y & 0xFFFFu) >> 6),
             ty1 = (int)((ent.y >> 16) >> 6);
         if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 32) {
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
 
 }  // namespace
 
-rdoom_status launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
+rdoom_status launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint32_t *counts,
                         uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
                         uint2 *hits, uint32_t *overflow, bool want_split, bool *launched, bool *used_split) {
   *launched = false, *used_split = false;
@@ -346,7 +359,7 @@ rdoom_status launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, co
   if (static_bytes + dyn_bytes(false) > 65536u) return RDOOM_OK;  // not launched: the caller flags every pose as "bins incomplete"
   // split lists need two more counters per tile (frames beyond ~4 000 tiles -- 5K and up -- keep whole-tile lists)
   const bool split = want_split && static_bytes + dyn_bytes(true) <= 65536u;
-  hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bin_threads), dyn_bytes(split), st, recs, sorted, counts, cap, tiles_x,
+  hipLaunchKernelGGL(bk, dim3(n_poses), dim3(bin_threads), dyn_bytes(split), st, recs, counts, cap, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, hits, overflow, split ? 1u : 0u);
   // (launch_setup ended with a check of its own launches: an error here is this launch's.  It is REPORTED, not turned into
   // "bins incomplete": the configuration was validated above, so a failure means the device or the queue is in trouble)

@@ -872,7 +872,6 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 }
 
 __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
-                                                    const uint4 *__restrict__ sorted,
                                                     const uint32_t *__restrict__ counts, uint32_t cap,
                                                     const PoseConst *__restrict__ poses, int width, int pitch, int height,
                                                     int tiles_x, int tiles_y, const uint2 *__restrict__ tile_hdr,
@@ -909,7 +908,7 @@ __global__ __launch_bounds__(256) void fixup_kernel(DeviceLevelView lv, const Tr
       unsigned long long key = ~0ull;
       uint32_t rec = NONE;
       if (e < hdr.y) {
-        rec = binned ? (entries[(size_t)pose * entry_cap + hdr.x + e] & ENTRY_REC_MASK) : sorted[(size_t)pose * cap + e].z;
+        rec = binned ? (entries[(size_t)pose * entry_cap + hdr.x + e] & ENTRY_REC_MASK) : e;  // (no bins: every record of the pose, near to far)
         const RasterRec r = prec[rec].r;
         const float *rwp = prec[rec].s.wp;  // (the 1/w plane lives in the shade part)
         const int x0 = (int)(r.bb0 & 0xFFFFu), y0 = (int)(r.bb0 >> 16), x1 = (int)(r.bb1 & 0xFFFFu),
@@ -992,7 +991,7 @@ FragmentPlan plan_fragment(int width, int pitch, int height, bool have_qtab) {
 }
 
 rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
-                             const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,
+                             const uint32_t *counts, uint32_t cap, const PoseConst *poses,
                              int width, int pitch, int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
                              const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,
                              bool vis16, uint32_t *prim_out, const float *ndc_tab, uint8_t *fb, uint32_t *fix_count,
@@ -1055,7 +1054,7 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
   hipLaunchKernelGGL(frag, fgrid_dim, dim3(64 * FRAG_WAVES), 0, st, static_cast<const FragConst *>(d_frag_const), lv.texels,
                      lv.colormap, recs, cap, poses, vis, n, fblocks, frag_chunk, qpp, qpr, wbpr, wbpp, bwl, W, H, fb, debug_leak_mod, qtab,
                      qtab_mode, (uint32_t)tiles_x, (uint32_t)(tiles_x * tiles_y));
-  hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, sorted, counts, cap, poses, W, pitch, H, tiles_x, tiles_y,
+  hipLaunchKernelGGL(fixup_kernel, dim3(64), dim3(256), 0, st, lv, recs, counts, cap, poses, W, pitch, H, tiles_x, tiles_y,
                      tile_hdr, entries, entry_cap, overflow, fix_count, fix_list, fix_cap, vis, vis16 ? 1u : 0u, prim_out, fb,
                      fix_count + 1);
 #ifdef RDOOM_FRAG_STATS

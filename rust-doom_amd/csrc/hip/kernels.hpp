@@ -24,18 +24,18 @@ constexpr uint32_t LONG_LIST = RDOOM_LONG_LIST, TILE_SPLIT = 0x80000000u;
 // Kernel 1: vertex stage, triangle setup, near-to-far record order (setup.hip)
 rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
                           const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
-                          TriRec *recs, uint32_t *visible, uint4 *sorted, uint32_t *counts, uint32_t *ghist, uint32_t cap,
+                          TriRec *recs, uint32_t *visible, uint32_t *counts, uint32_t *ghist, uint32_t cap,
                           uint32_t *mismatch_flag);  // set when the set-up kernel rejects a triangle the cull kernel kept
 size_t setup_histogram_bytes(uint32_t max_poses);  // scratch of the counting sort (per pose: one counter per depth bucket)
 // Kernel 1b: per-tile triangle lists (bin.hip).  *launched = false: the frame has too many tiles for the kernel's LDS counters --
 // nothing was launched and the caller must flag every pose as "bins incomplete".  A launch that FAILS is an error.
-rdoom_status launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint4 *sorted, const uint32_t *counts,
+rdoom_status launch_bin(hipStream_t st, uint32_t n_poses, const TriRec *recs, const uint32_t *counts,
                         uint32_t cap, int tiles_x, int tiles_y, uint2 *tile_hdr, uint32_t *entries, uint32_t entry_cap,
                         uint2 *hits, uint32_t *overflow,
                         bool want_split, bool *launched, bool *used_split);  // lists of more than LONG_LIST entries per quadrant, if the counters fit (bin.hip)
 // Kernel 2: tiled rasteriser -> visibility words (raster.hip)
 rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
-                           const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
+                           const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
                            const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out,
                            uint32_t *qtab,  // qtab (optional): per (pose, tile, quadrant) the record all its pixels show, or NONE
@@ -56,7 +56,7 @@ struct FragmentPlan {
 FragmentPlan plan_fragment(int width, int pitch, int height, bool have_qtab);
 // Kernels 3 + 4: fragment kernel -> palette indices, then the alpha-leak fixup (fragment.hip)
 rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
-                             const uint4 *sorted, const uint32_t *counts, uint32_t cap, const PoseConst *poses,
+                             const uint32_t *counts, uint32_t cap, const PoseConst *poses,
                              int width, int pitch,  // the frame's width; pixels between rows of visibility words / framebuffer bytes
                              int height, int tiles_x, int tiles_y, const uint2 *tile_hdr,
                              const uint32_t *entries, uint32_t entry_cap, const uint32_t *overflow, uint32_t *vis,

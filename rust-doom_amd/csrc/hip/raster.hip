@@ -381,7 +381,6 @@ constexpr uint32_t RASTER_WAVES = RDOOM_RASTER_WAVES;  // tiles (= waves) per wo
 // it was before such lists existed (the caller chooses per render: renderer.hip)
 template <bool STATS, bool VIS16, bool PRIM, bool SKIPVIS, bool SPLIT>
 __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void raster_wave_kernel(DeviceLevelView lv, const TriRec *__restrict__ recs,
-                                                             const uint4 *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts, uint32_t cap,
                                                              uint32_t n_poses, int width, int height, int tiles_x,
                                                              int tiles_y, const uint2 *__restrict__ tile_hdr,
@@ -421,7 +420,6 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   const int tx0 = (int)tile_x * TILE_W, ty0 = (int)tile_y * TILE_H;
   const int lx = (lane & 7) * 4, ly = (lane >> 3) * 4;  // this lane's 4x4 block inside a quadrant
   const TriRec *prec = recs + (size_t)pose * cap;
-  const uint4 *psorted = sorted + (size_t)pose * cap;
   // (three independent scalar loads in flight at once, not a chain: the header is read whether or not it will be used)
   const uint32_t over = overflow[pose], all_visible = counts[pose];
   const uint2 hdr_binned = tile_hdr[(size_t)pose * T + tile];
@@ -461,8 +459,8 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
         qb = e >> 28;  // exact quadrant tests done by the binning kernel
       } else {
         // pose without complete bins: every visible triangle is a candidate; bbox, then the exact quadrant tests
-        const uint4 bb = psorted[i];  // (bb0, bb1, record index, depth bucket), near to far
-        cand = bb.z;
+        const uint4 bb = reinterpret_cast<const uint4 *>(&prec[i])[3];  // (bb0, bb1, flags, pad): records lie near to far
+        cand = i;
         const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
         if (x0 <= tx0 + 63 && x1 >= tx0 && y0 <= ty0 + 63 && y1 >= ty0) {
           const uint4 *rp = reinterpret_cast<const uint4 *>(&prec[cand]);
@@ -968,7 +966,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
 }  // namespace
 
 rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const TriRec *recs,
-                           const uint4 *sorted, const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
+                           const uint32_t *counts, uint32_t cap, int width, int height, int tiles_x,
                            int tiles_y, const uint2 *tile_hdr, const uint32_t *entries, uint32_t entry_cap,
                            const uint32_t *overflow, uint32_t *vis, bool vis16, uint32_t *prim_out, uint32_t *qtab,
                            bool skip_described_vis, bool split_lists, bool bins_launched) {
@@ -1007,7 +1005,7 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
 #else
   const dim3 rgrid((uint32_t)tiles_x * 8u, (uint32_t)tiles_y, groups);
 #endif
-  hipLaunchKernelGGL(rk, rgrid, dim3(64 * RASTER_WAVES), 0, st, lv, recs, sorted, counts, cap, n, width, height, tiles_x,
+  hipLaunchKernelGGL(rk, rgrid, dim3(64 * RASTER_WAVES), 0, st, lv, recs, counts, cap, n, width, height, tiles_x,
                      tiles_y, tile_hdr, entries, entry_cap, overflow, vis, prim_out, (dbg.no_cover ? 1u : 0u) | (dbg.no_pair ? 2u : 0u),
                      qtab, settle ? 1u : 0u, d_stats);
 #ifdef RDOOM_CENSUS_TWO

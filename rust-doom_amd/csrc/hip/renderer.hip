@@ -45,7 +45,7 @@ struct rdoom_level {
   void *d_tris = nullptr, *d_texels = nullptr, *d_sky = nullptr, *d_cmap = nullptr, *d_slices = nullptr;
   std::vector<LevelSlice> slices;      // host copy of the slice table
   std::vector<uint32_t> slice_objects; // 1 + the largest object id each level draws
-  uint32_t ntri = 0;        // the LARGEST level's triangle count: a pose's records, visible list, sorted list have this stride
+  uint32_t ntri = 0;        // the LARGEST level's triangle count: a pose's records and visible list have this stride
   uint32_t n_objects = 1;   // 1 + the largest object id any level of the set draws
 };
 
@@ -60,7 +60,6 @@ struct rdoom_batch {
   PoseConst *d_poses = nullptr;
   TriRec *d_recs = nullptr;   // max_poses x cap records in near-to-far order (setup -> bin, raster, fragment)
   uint32_t *d_visible = nullptr;  // max_poses x cap: the visible triangles of each pose (cull kernel -> set-up kernel)
-  uint4 *d_sorted = nullptr;  // per pose: (bbox, record index, depth bucket) near-to-far (coarse test input)
   uint2 *d_tile_hdr = nullptr;     // per (pose, tile): (first entry, entry count)
   uint32_t *d_entries = nullptr;   // per pose: entry_cap tile-list entries (record index | quadrant mask << 28)
   uint2 *d_hits = nullptr;         // per pose: entry_cap (entry, tile) pairs: the binning kernel's count pass -> its fill pass
@@ -450,7 +449,7 @@ void rdoom_batch_destroy(rdoom_batch *b) {
     for (auto &t : g_host_t) t = 0;
   }
 #endif
-  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_visible, (void *)b->d_sorted, (void *)b->d_tile_hdr, (void *)b->d_entries, (void *)b->d_hits,
+  for (void *p : {(void *)b->d_poses, (void *)b->d_recs, (void *)b->d_visible, (void *)b->d_tile_hdr, (void *)b->d_entries, (void *)b->d_hits,
                   (void *)b->d_overflow, (void *)b->d_zeroed, (void *)b->d_fix_list, (void *)b->d_vis,
                   (void *)b->d_prim, (void *)b->d_fb, (void *)b->d_qtab, b->d_frag_const})
     if (p) (void)hipFree(p);
@@ -492,7 +491,6 @@ rdoom_status rdoom_batch_create(const rdoom_level *level, uint32_t width, uint32
   hipError_t e = hipMalloc((void **)&b->d_poses, sizeof(PoseConst) * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, sizeof(TriRec) * (size_t)b->cap * max_poses);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_visible, sizeof(uint32_t) * (size_t)b->cap * max_poses);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_sorted, sizeof(uint4) * (size_t)b->cap * max_poses);
   b->n_tiles = ((width + TILE_W - 1) / TILE_W) * ((height + TILE_H - 1) / TILE_H);
   // tile-list entries per pose; beyond it the pose is rasterised from its sorted list (slow: every tile scans every visible
   // triangle).  A long tile's list is stored per quadrant (bin.hip), an entry once per quadrant it touches, so the array is
@@ -643,7 +641,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   HIP_TRY(hipMemsetAsync(b->d_zeroed, 0, (size_t)((const char *)b->d_ghist - (const char *)b->d_zeroed) + setup_histogram_bytes(n), st));
   if (lv->ntri)
     if (rdoom_status rs = launch_setup(st, n, lv->view, b->d_poses, object_modelviews ? (const ObjectConst *)b->d_objects : nullptr,
-                                       lv->n_objects, W, H, kinds_mask, b->d_recs, b->d_visible, b->d_sorted, b->d_counts,
+                                       lv->n_objects, W, H, kinds_mask, b->d_recs, b->d_visible, b->d_counts,
                                        b->d_ghist, b->cap, b->d_fix_count + 2))
       return rs;
   HT_MARK(3);
@@ -651,7 +649,7 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   bool split_lists = false;  // long tile lists stored per quadrant this render (binning kernel and rasteriser must agree)
   bool bins = false;
   if (lv->ntri && !rdoom::debug_options().no_bins)
-    if (rdoom_status rs = launch_bin(st, n, b->d_recs, b->d_sorted, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
+    if (rdoom_status rs = launch_bin(st, n, b->d_recs, b->d_counts, b->cap, tiles_x, tiles_y, b->d_tile_hdr, b->d_entries,
                                      b->entry_cap, b->d_hits, b->d_overflow, !rdoom::debug_options().no_split, &bins, &split_lists))
       return rs;
   if (!bins) {
@@ -664,13 +662,13 @@ static rdoom_status render_impl(rdoom_batch *b, const rdoom_pose *poses, const u
   const FragmentPlan plan = plan_fragment(W, PITCH, H, b->d_qtab != nullptr);
   // (the rasteriser's frame is PITCH pixels wide: the padding columns of a width that is not a multiple of 4 are pixels no
   // bounding box reaches -- they stay uncovered, and the quadrants they lie in simply never count as covered)
-  if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, PITCH, H, tiles_x, tiles_y,
+  if (rdoom_status rs = launch_raster(st, n, lv->view, b->d_recs, b->d_counts, b->cap, PITCH, H, tiles_x, tiles_y,
                                       b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16, prim_out, b->d_qtab,
                                       plan.skip_described_vis, split_lists, bins))
     return rs;
   if (marks) HIP_TRY(hipEventRecord(ev[2], st));
   HT_MARK(5);
-  if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_sorted, b->d_counts, b->cap, b->d_poses, W, PITCH, H, tiles_x,
+  if (rdoom_status rs = launch_fragment(st, n, lv->view, b->d_recs, b->d_counts, b->cap, b->d_poses, W, PITCH, H, tiles_x,
                                         tiles_y, b->d_tile_hdr, b->d_entries, b->entry_cap, b->d_overflow, b->d_vis, b->vis16,
                                         prim_out, b->d_ndc, b->d_fb, b->d_fix_count, b->d_fix_list, b->fix_cap, b->d_qtab, b->d_frag_const,
                                         &b->frag_const_ready, plan))

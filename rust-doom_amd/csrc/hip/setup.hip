@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, RDOOM_SETUP_OCC) void setup_kernel(DeviceLevel
                                                     const ObjectConst *__restrict__ objects, uint32_t n_objects,
                                                     int width, int height, uint32_t kinds_mask,
                                                     const uint32_t *__restrict__ visible, TriRec *__restrict__ recs,
-                                                    uint4 *__restrict__ sorted, const uint32_t *__restrict__ counts,
+                                                    const uint32_t *__restrict__ counts,
                                                     uint32_t *__restrict__ ghist, uint32_t cap,
                                                     uint32_t *__restrict__ mismatch_flag, uint32_t place_groups) {
   const uint32_t pose = blockIdx.x / place_groups, pgroup = blockIdx.x - pose * place_groups, n = counts[pose];
@@ -403,12 +403,12 @@ __global__ __launch_bounds__(256, RDOOM_SETUP_OCC) void setup_kernel(DeviceLevel
   const ObjectConst *objs = objects ? objects + (size_t)pose * n_objects : nullptr;
   const uint32_t *pvisible = visible + (size_t)pose * cap;
   TriRec *prec = recs + (size_t)pose * cap;
-  uint4 *psorted = sorted + (size_t)pose * cap;
   uint32_t *phist = ghist + (size_t)pose * SORT_BUCKETS;
   // positions: scanned histogram + rank.  The ranks of a chunk of 256 records are counted in LDS and each bucket that
   // occurs claims its run with ONE global atomic (a returning global atomic per record serialises on the few buckets a
   // pose's triangles crowd into)
   __shared__ uint32_t lcount[SORT_BUCKETS], lbase[SORT_BUCKETS];
+  __shared__ uint4 wstage[4][32 * 8];  // per wave: 32 records of 128 bytes on their way to memory (below)
   if (pgroup * 256u >= n) return;  // uniform: nothing for this workgroup
   for (uint32_t i = threadIdx.x; i < SORT_BUCKETS; i += 256u) lcount[i] = 0;
   __syncthreads();
@@ -458,13 +458,31 @@ __global__ __launch_bounds__(256, RDOOM_SETUP_OCC) void setup_kernel(DeviceLevel
     __syncthreads();
     if (valid && lrank == 0u) lbase[bucket] = atomicAdd(&phist[bucket], lcount[bucket]);
     __syncthreads();
-    if (valid) {
-      const uint32_t pos = lbase[bucket] + lrank;
+    // The record goes to its near-to-far position as ONE 128-byte line written by EIGHT lanes (round 6): a lane storing its own
+    // record issued eight 16-byte stores, each of a wave's store instructions touching 64 different lines.  Half a wave at a time
+    // parks its 32 records in the wave's LDS stage (4 KiB; 16-byte words swizzled so that neither side conflicts), then lane l
+    // of the whole wave stores word l & 7 of records (l >> 3) + 8 j: a store instruction writes eight whole lines.
+    const uint32_t pos = valid ? lbase[bucket] + lrank : NONE;
+    {
+      const uint32_t lane = threadIdx.x & 63u, word = lane & 7u;
+      uint4 *stage = wstage[threadIdx.x >> 6];
       const uint4 *v = reinterpret_cast<const uint4 *>(&rec);
-      uint4 *dst = reinterpret_cast<uint4 *>(&prec[pos]);
 #pragma unroll
-      for (uint32_t k = 0; k < 8u; k++) dst[k] = v[k];
-      psorted[pos] = make_uint4(rec.r.bb0, rec.r.bb1, pos, bucket);
+      for (uint32_t h = 0; h < 2u; h++) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the stage's previous readers are done
+        if (valid && (lane >> 5) == h) {
+          const uint32_t r = lane & 31u;
+#pragma unroll
+          for (uint32_t k = 0; k < 8u; k++) stage[r * 8u + (k ^ ((r >> 1) & 7u))] = v[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+          const uint32_t r = (lane >> 3) + 8u * j;
+          const uint32_t pos_r = (uint32_t)__shfl((int)pos, (int)(32u * h + r));
+          if (pos_r != NONE) reinterpret_cast<uint4 *>(&prec[pos_r])[word] = stage[r * 8u + (word ^ ((r >> 1) & 7u))];
+        }
+      }
     }
     __syncthreads();
     if (valid && lrank == 0u) lcount[bucket] = 0u;  // ready for the next chunk (its atomics follow the barrier below)
@@ -476,7 +494,7 @@ __global__ __launch_bounds__(256, RDOOM_SETUP_OCC) void setup_kernel(DeviceLevel
 
 rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelView &lv, const PoseConst *poses,
                           const ObjectConst *objects, uint32_t n_objects, int width, int height, uint32_t kinds_mask,
-                          TriRec *recs, uint32_t *visible, uint4 *sorted, uint32_t *counts, uint32_t *ghist, uint32_t cap,
+                          TriRec *recs, uint32_t *visible, uint32_t *counts, uint32_t *ghist, uint32_t cap,
                           uint32_t *mismatch_flag) {
   // (counts and ghist arrive zeroed: the caller clears them together with its other per-render words in one fill)
   // several workgroups per pose on large levels (each takes a share of the clusters): one would walk them serially
@@ -488,7 +506,7 @@ rdoom_status launch_setup(hipStream_t st, uint32_t n_poses, const DeviceLevelVie
   hipLaunchKernelGGL(sort_scan_kernel, dim3(n_poses), dim3(256), 0, st, ghist);
   const uint32_t place_groups = std::min<uint32_t>((cap + 1023u) / 1024u, 16u);  // about a fifth of a level is visible: one or two chunks of 256 records each
   hipLaunchKernelGGL(setup_kernel, dim3(n_poses * place_groups), dim3(256), 0, st, lv, poses, objects, n_objects, width, height,
-                     kinds_mask, visible, recs, sorted, counts, ghist, cap, mismatch_flag, place_groups);
+                     kinds_mask, visible, recs, counts, ghist, cap, mismatch_flag, place_groups);
   // a launch that failed (an invalid configuration) must not go unreported: the binning kernel would build its lists from stale
   // records and counts and the render would still return RDOOM_OK
   HIP_TRY(hipGetLastError());
