@@ -197,10 +197,13 @@ __global__ __launch_bounds__(BIN_THREADS, RDOOM_BIN_OCC) void bin_kernel(const T
             const int x0 = (int)(bb.x & 0xFFFFu), y0 = (int)(bb.x >> 16), x1 = (int)(bb.y & 0xFFFFu), y1 = (int)(bb.y >> 16);
             const uint32_t tr = trange[lo[u]];
             const int tx0 = (int)(tr & 0xFFu), ty0 = (int)((tr >> 8) & 0xFFu), ntx = (int)(tr >> 16);
-            const int ty = (int)(((float)t + 0.5f) / (float)ntx), tx = (int)t - ty * ntx;  // t / ntx (t < 8192: exact)
+            // t / ntx for t < 8192, ntx <= 128: (t + 0.5) / ntx lies at least 1 / 256 away from an integer and v_rcp_f32's error
+            // (one ulp) moves the product by less than 8192.5 * 2^-22 < 1 / 256: exact without the IEEE division's dozen instructions
+            const int ty = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ntx)), tx = (int)t - ty * ntx;
             const uint4 c0 = coef[lo[u]][0], c1 = coef[lo[u]][1], c2 = coef[lo[u]][2];
-            if (tile_may_touch(c0, c1, c2, (tx0 + tx) * 64, (ty0 + ty) * 64))
-              qm[u] = tile_quadrant_mask(c0, c1, c2, x0, y0, x1, y1, (tx0 + tx) * 64, (ty0 + ty) * 64);
+            // (no whole-tile test first: a quadrant's corner values ask for no less than the tile's, so the mask is zero wherever
+            // the tile test fails -- and with 64 pairs per wave some lane passed it nearly always: 30 instructions per pair for nothing)
+            qm[u] = tile_quadrant_mask(c0, c1, c2, x0, y0, x1, y1, (tx0 + tx) * 64, (ty0 + ty) * 64);
             tile[u] = (uint32_t)((ty0 + ty) * tiles_x + tx0 + tx);
           }
         }

@@ -5,6 +5,8 @@
 //            floor(x * RN(1/y)) and floor(x / y) can disagree) and at pseudo-random positions:
 //            mod_cert(x, r, y) must imply floor(x * RN(1/y)) == floor(x / y)
 //   sweep 3  v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 == scalar fmaf / * / + on pseudo-random operands
+//   sweep 4  the binning kernel's pair -> tile row: (int)((t + 0.5f) * v_rcp_f32(ntx)) == t / ntx for every t < 8192,
+//            1 <= ntx <= 128 (bin.hip; mismatches are added to sweep 3's count)
 // Takes a few seconds on an MI355X; used by tests/test_gpu_fastmath.py.
 #include <hip/hip_runtime.h>
 
@@ -113,6 +115,16 @@ __global__ void sweep_packed(unsigned long long *out) {  // out[7] mismatches
   atomicAdd(&out[7], n);
 }
 
+__global__ void sweep_tile_index(unsigned long long *out) {  // out[7] += mismatches
+  const uint32_t ntx = blockIdx.x + 1u;  // 1..128
+  unsigned long long n = 0;
+  for (uint32_t t = threadIdx.x; t < 8192u; t += blockDim.x) {
+    const int ty = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ntx));
+    if ((uint32_t)ty != t / ntx) n++;
+  }
+  if (n) atomicAdd(&out[7], n);
+}
+
 }  // namespace
 
 extern "C" rdoom_status rdoom_selftest_fastmath(uint64_t out_counts[8]) {
@@ -124,6 +136,7 @@ extern "C" rdoom_status rdoom_selftest_fastmath(uint64_t out_counts[8]) {
     hipLaunchKernelGGL(sweep_div, dim3(4096), dim3(256), 0, nullptr, d);
     hipLaunchKernelGGL(sweep_mod, dim3(4096), dim3(256), 0, nullptr, d);
     hipLaunchKernelGGL(sweep_packed, dim3(1024), dim3(256), 0, nullptr, d);
+    hipLaunchKernelGGL(sweep_tile_index, dim3(128), dim3(256), 0, nullptr, d);
     e = hipGetLastError();
   }
   unsigned long long h[8] = {};
