@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
       if (in_range & mod_ok & opaque) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-          const uint32_t c0 = cmap[ci[2 * p]], c1 = cmap[ci[2 * p + 1]];
+          const uint32_t c0 = (DBG & 8) ? (ci[2 * p] & 0xFFu) : cmap[ci[2 * p]], c1 = (DBG & 8) ? (ci[2 * p + 1] & 0xFFu) : cmap[ci[2 * p + 1]];
           out[p >> 1] |= (c0 | (c1 << 8)) << (16 * (p & 1));
         }
         done = true;
@@ -553,7 +553,10 @@ __global__ __launch_bounds__(64 * RDOOM_FRAG_WAVES) FRAG_OCCUPANCY void fragment
         done = true;
       }
     }
-    if (done & valid) {
+    if (done & valid & (!(DBG & 4) || out[0] == 0x12345679u)) {  // (DBG & 4, timing experiment: practically never)
+      if (DBG & 16) {  // timing experiment (wrong image): the block's 512 bytes as ONE contiguous run -- what would whole-line stores cost?
+        *reinterpret_cast<uint2 *>(pfb_bytes + (size_t)wb * 512u + lane * 8u) = make_uint2(out[0], out[NQ - 1]);
+      } else
       if (NQ == 2)
         *reinterpret_cast<uint2 *>(pfb_bytes + q0 * 4u) = make_uint2(out[0], out[NQ - 1]);
       else
@@ -1027,9 +1030,19 @@ rdoom_status launch_fragment(hipStream_t st, uint32_t n_poses, const DeviceLevel
   auto frag = nq == 2 ? (vis16 ? fragment_kernel<2, 0, true> : fragment_kernel<2, 0, false>)
                       : (vis16 ? fragment_kernel<1, 0, true> : fragment_kernel<1, 0, false>);
 #ifdef RDOOM_TIMING_EXPERIMENTS  // wrong images by design: never in the shipped library
-  if (getenv("RDOOM_FRAG_DBG") && atoi(getenv("RDOOM_FRAG_DBG")) == 2)
-    frag = nq == 2 ? (vis16 ? fragment_kernel<2, 2, true> : fragment_kernel<2, 2, false>)
-                   : (vis16 ? fragment_kernel<1, 2, true> : fragment_kernel<1, 2, false>);
+  // RDOOM_FRAG_DBG = bit set: 2 no texel loads, 4 no framebuffer stores, 8 no COLORMAP look-ups in LDS (two quads per lane, 16-bit words only)
+  if (getenv("RDOOM_FRAG_DBG") && nq == 2 && vis16) {
+    switch (atoi(getenv("RDOOM_FRAG_DBG"))) {
+      case 2: frag = fragment_kernel<2, 2, true>; break;
+      case 4: frag = fragment_kernel<2, 4, true>; break;
+      case 8: frag = fragment_kernel<2, 8, true>; break;
+      case 6: frag = fragment_kernel<2, 6, true>; break;
+      case 10: frag = fragment_kernel<2, 10, true>; break;
+      case 14: frag = fragment_kernel<2, 14, true>; break;
+      case 16: frag = fragment_kernel<2, 16, true>; break;
+      default: break;
+    }
+  }
 #endif
   const uint32_t qtab_mode = qtab ? plan.qtab_mode : 0u;
   if (!*frag_const_ready) {  // constant for the life of the batch: written once

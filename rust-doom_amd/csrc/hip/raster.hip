@@ -57,7 +57,7 @@ __device__ __forceinline__ void raster_entry(const DeviceLevelView &lv, const Tr
                                              int x1, int y1, uint32_t flags, uint32_t ridx, int bx, int by, float pxlo,
                                              float pxhi, float pylo, float pyhi, uint32_t (&best_d)[16],
                                              uint32_t (&best_r)[16], uint32_t &lane_far, ShadeFetch fetch_shade,
-                                             unsigned long long (&st)[16]) {
+                                             unsigned long long (&st)[20]) {
     // lane-level exact rejection over my 4x4 block.  Early-z first (most rejected triangles are simply hidden):
     // nearest depth of the plane over the block against the farthest depth I still hold
     const float zn = fmaf(za, pos(za) ? pxlo : pxhi, fmaf(zb, pos(zb) ? pylo : pyhi, zc));
@@ -80,7 +80,7 @@ __device__ __forceinline__ void raster_entry(const DeviceLevelView &lv, const Tr
     const float rwf = fmaf(wa, pos(wa) ? pxhi : pxlo, fmaf(wb, pos(wb) ? pyhi : pylo, wc));
     const bool need = need0 & (rwf > 0.0f);
     if (!__any(need)) return;
-    if (STATS) st[2]++, st[3] += (unsigned long long)__popcll(__ballot(need));
+    if (STATS) st[2]++, st[3] += (unsigned long long)__popcll(__ballot(need)), st[16] += need ? 1ull : 0ull;  // [16]: THIS lane's bodies in the current pass
     // Fast path (exact): block fully inside the bbox, whole block inside the depth range and in front
     // of the eye, texture rectangle fully opaque.  Edge ties and depth ties are only *detected* here and
     // replayed through the general path below, so the result is the same as running it everywhere.
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
                                                              uint32_t *__restrict__ prim_out, uint32_t no_cover,
                                                              uint32_t *__restrict__ qtab, uint32_t settled,
                                                              unsigned long long *__restrict__ stats) {
-  unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __shared__ uint32_t wq[RASTER_WAVES][64];
   __shared__ uint4 wrec[RASTER_WAVES][64][4];  // per wave: 15 words of each of the 64 gathered raster records
   // per entry: a sign-blind hash of each edge's three coefficients (a shared edge has exactly negated coefficients in the two
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
           }
         }
         if (STATS && lane == 0)
-          for (int k = 0; k < 16; k++) atomicAdd(&stats[k], st[k]);
+          for (int k = 0; k < 20; k++) atomicAdd(&stats[k], st[k]);
         RT_MARK(2);  // tile-level shortcut, taken
         RT_FLUSH();
         return;
@@ -902,6 +902,10 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
         RT_MARK(8);  // other entry: record broadcast, rejection tests, pixel bodies
       }
     }
+    if (STATS) {  // the census a per-lane choice of entries would be judged by: the pass's bodies (st[2]) against the most any ONE lane needed
+      const uint32_t mx = wave_max_u32((uint32_t)st[16]);
+      st[17] += (unsigned long long)mx, st[18] += mx != 0u ? 1ull : 0ull, st[16] = 0ull;
+    }
     // ---- this quadrant's visibility words ------------------------------------------------------------------------
     // One record after all?  (The shortcut above needs the winner to lie strictly in front of everything else over the whole
     // quadrant; a quadrant can still end up with one winner.)  Lane 0's first pixel lies inside the frame; lanes whose block
@@ -960,7 +964,7 @@ __global__ __launch_bounds__(64 * RDOOM_RASTER_WAVES, RDOOM_RASTER_OCC) void ras
   }
   RT_FLUSH();
   if (STATS && lane == 0)
-    for (int k = 0; k < 16; k++) atomicAdd(&stats[k], st[k]);
+    for (int k = 0; k < 20; k++) atomicAdd(&stats[k], st[k]);
 }
 
 }  // namespace
@@ -977,8 +981,8 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
   const rdoom::DebugOptions &dbg = rdoom::debug_options();
   unsigned long long *d_stats = nullptr;
   if (dbg.raster_stats) {
-    HIP_TRY(hipMalloc((void **)&d_stats, 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMalloc((void **)&d_stats, 20 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 20 * sizeof(unsigned long long), st));
   }
   const bool skip = skip_described_vis && qtab != nullptr;  // (without a table every visibility word is needed)
   auto pick = [&](auto stats, auto skipvis, auto splt) {
@@ -1034,7 +1038,7 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
   }
 #endif
   if (d_stats) {
-    unsigned long long h[16];
+    unsigned long long h[20];
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     (void)hipFree(d_stats);
     {  // census of the tile lists' lengths (a tile with more than 64 entries gets a list per quadrant: bin.hip)
@@ -1066,6 +1070,9 @@ rdoom_status launch_raster(hipStream_t st, uint32_t n_poses, const DeviceLevelVi
             h[0] / waves, h[1] / waves, h[10] / waves, h[2] / waves, h[2] ? (double)h[3] / h[2] : 0.0, h[4] / waves,
             h[4] ? (double)h[5] / h[4] : 0.0, h[6] / waves, h[6] ? (double)h[7] / h[6] : 0.0,
             h[6] ? (double)h[12] / h[6] : 0.0, h[6] ? (double)h[13] / h[6] : 0.0, h[15] / waves, h[14] / waves, h[9] / waves, h[11] / waves, h[8] / waves, h[8], waves);
+    fprintf(stderr, "[rdoom stats] sixteen-pixel bodies: %llu in %llu passes that ran any (%.2f per such pass, %.1f lanes each); the most ONE lane needed, summed over those passes: %llu (%.2f per pass) -- "
+            "what a body with a per-lane choice of entry would run; all needs / 64: %.2f per pass\n",
+            h[2], h[18], h[18] ? (double)h[2] / h[18] : 0.0, h[2] ? (double)h[3] / h[2] : 0.0, h[17], h[18] ? (double)h[17] / h[18] : 0.0, h[18] ? (double)h[3] / 64.0 / h[18] : 0.0);
   }
   return RDOOM_OK;
 }
