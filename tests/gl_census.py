@@ -38,6 +38,7 @@ ROUNDING_MARGIN = 2.0 ** -11      # binary32 v_dist vs float64 at the pixel cent
 # frames through oracle_render_varyings: median 0.3, 99.9 % below 8.7, maximum 36 (a wall seen edge-on: 128 texels over
 # 4 pixels, condition sum 1.4e5, 0.025 texels off).  Well-conditioned pixels get a far smaller margin than before.
 ROUNDING_K = 64.0
+ROW_DIVISION_MARGIN = 2.0 ** -17   # COLORMAP rows: see fragment_exact
 CLASSES = ('edge', 'alpha texel boundary', 'depth tie', 'texel boundary', 'colormap-row boundary', 'other')
 
 
@@ -427,5 +428,25 @@ def fragment_exact(oracle, lvl, time, lights, gl_rgb, gl_prim, gl_var):
                     ix, iy = int(math.floor(fx + dx * 1.0 / 32)) % sw, int(math.floor(fy + dy * 1.0 / 32)) % sh
                     near.append(tuple(int(c) for c in playpal[cmap0[int(sky[iy, ix]) & 255]]))
             sky_explained += tuple(int(c) for c in gl_rgb[y, x]) in near
+    # Flat / wall / decor disagreements (none with SwiftShader; a handful per hundred million pixels with Mesa's llvmpipe): GLSL does
+    # not ask for a correctly rounded quotient -- Mesa evaluates `DIST_SCALE / (v_dist + DIST_SCALE)` as DIST_SCALE * (1 / x), an
+    # ulp away from the IEEE quotient in a quarter of all cases -- and the palette's NEAREST fetch turns `1.0 - light` into a row
+    # by the sampler's own floor.  Such a pixel counts as explained only if (1 - light) * 32, evaluated in binary32 as the
+    # shader text reads, lies within ROW_DIVISION_MARGIN (2^-17 of a row: three ulps of a value below 32) of a row boundary
+    # AND the row across that boundary, with the SAME texel, gives exactly the colour GL wrote.
+    row_explained = 0
+    if by_kind['flat'] + by_kind['wall'] + by_kind['decor']:
+        f64 = F64Frame(lvl, np.eye(4, dtype=np.float32).reshape(16), np.eye(4, dtype=np.float32).reshape(16), time, lights, 16, 16)
+        cmap = np.asarray(g('colormap')).reshape(32, 256)
+        all_kinds = draws[np.clip(np.searchsorted(first, gl_prim, side='right') - 1, 0, len(draws) - 1), 0]
+        for y, x in zip(*np.nonzero(bad & (all_kinds != KIND_SKY) & (gl_prim != 0xFFFFFFFF))):
+            fr = f64.fragment(int(gl_prim[y, x]), float(gl_var[y, x, 0]), float(gl_var[y, x, 1]), float(gl_var[y, x, 2]), binary32=True)
+            if not fr['opaque'] or fr['row_margin'] > ROW_DIVISION_MARGIN:
+                continue
+            a = f64.atlas[f64._tri(int(gl_prim[y, x]))['kind']]
+            texel = int(a[fr['texel'][1], fr['texel'][0]]) & 255
+            # (fr['row'] is the float64 evaluation's row: the oracle's binary32 one -- which disagreed -- is it or a neighbour)
+            near = [tuple(int(c) for c in playpal[cmap[r, texel]]) for r in (fr['row'] - 1, fr['row'], fr['row'] + 1) if 0 <= r < 32]
+            row_explained += tuple(int(c) for c in gl_rgb[y, x]) in near
     return {'pixels': int(drawn.sum()), 'disagree': int(bad.sum()), 'by_kind': by_kind, 'sky_sampler_boundary': int(sky_explained),
-            'mask': bad}
+            'row_division_boundary': int(row_explained), 'mask': bad}

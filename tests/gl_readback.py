@@ -28,6 +28,13 @@ attribute, which reads back WHICH primitive SwiftShader's rasteriser + depth tes
 in ES 3.00); `mode='varyings'` replaces the colour write by `vec3(v_tile_uv, v_dist)` into a float target, which reads
 back the varyings SwiftShader interpolated -- GL leaves their precision to the implementation.
 
+A SECOND GL IMPLEMENTATION (round 6): Mesa's llvmpipe, desktop OpenGL 4.5 core profile, opened without an X server through
+the DRI driver's own extension table (tests/mesa_headless.c).  There NOTHING in the shader text is patched: the engine's
+`#version 140` line (engine/src/platform.rs:5, engine/src/shaders.rs:45) is prepended as the engine prepends it, `u_lights` is
+the `samplerBuffer` the reference declares (a GL_R8 buffer texture, as game_shaders.rs:152-159 creates it), `precision mediump
+float;` stays (desktop GLSL ignores it).  `GLReference(level, backend='mesa')`; the auxiliary passes replace the colour write
+the same way.  tests/test_gl_readback_mesa.py holds what is asserted about it.
+
 Test infrastructure: imported by tests/golden/make_gl_readback.py (fixture generator) and tests/test_gl_readback.py.
 """
 import ctypes
@@ -38,6 +45,10 @@ import numpy as np
 
 SWIFTSHADER_DIR = os.environ.get(
     'RDOOM_SWIFTSHADER_DIR', '/usr/local/lib/python3.10/dist-packages/kaleido/executable/bin/swiftshader')
+MESA_DRIVER = os.environ.get('RDOOM_MESA_SWRAST', '/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so')
+MESA_GLAPI = os.environ.get('RDOOM_MESA_GLAPI', '/usr/lib/x86_64-linux-gnu/libglapi.so.0')
+ENGINE_VERSION_LINE = '#version 140\n'   # engine/src/shaders.rs:45 with platform::GLSL_VERSION_STRING = "140" (engine/src/platform.rs:5)
+GL_TEXTURE_BUFFER = 0x8C2A
 REFERENCE_SHADERS = os.environ.get('RDOOM_REFERENCE_SHADERS', '/root/reference/assets/shaders')
 CLEAR_RGB = (15, 18, 23)   # (0.06, 0.07, 0.09) as 8-bit UNORM (window.rs:42)
 KIND_FLAT, KIND_WALL, KIND_DECOR, KIND_SKY = 0, 1, 2, 3
@@ -63,18 +74,25 @@ GL_COLOR_BUFFER_BIT, GL_DEPTH_BUFFER_BIT, GL_TRIANGLES = 0x4000, 0x0100, 0x0004
 GL_UNPACK_ALIGNMENT, GL_PACK_ALIGNMENT = 0x0CF5, 0x0D05
 
 
-def available():
-    return (os.path.exists(os.path.join(SWIFTSHADER_DIR, 'libEGL.so')) and
-            os.path.exists(os.path.join(REFERENCE_SHADERS, 'static.frag')))
+def available(backend='swiftshader'):
+    if not os.path.exists(os.path.join(REFERENCE_SHADERS, 'static.frag')):
+        return False
+    if backend == 'mesa':
+        return os.path.exists(MESA_DRIVER) and os.path.exists(MESA_GLAPI) and os.path.exists('/usr/include/GL/internal/dri_interface.h')
+    return os.path.exists(os.path.join(SWIFTSHADER_DIR, 'libEGL.so'))
 
 
-def patch_shader(text, stage, mode='colour'):
-    """The reference's shader text with only the GLSL ES 3.00 necessities changed (module docstring, 1-3).
+def patch_shader(text, stage, mode='colour', backend='swiftshader'):
+    """The reference's shader text with only the GLSL ES 3.00 necessities changed (module docstring, 1-3); backend 'mesa'
+    (desktop GL): the text AS IT IS behind the engine's own version line.
     mode 'ids' / 'varyings': the auxiliary passes (the colour write is replaced, nothing else)."""
-    text = text.replace('precision mediump float;', '')
-    head = '#version 300 es\nprecision highp float;\nprecision highp int;\nprecision highp sampler2D;\n'
-    text = text.replace('uniform samplerBuffer u_lights;', 'uniform sampler2D u_lights;')
-    text = text.replace('texelFetch(u_lights, a_light)', 'texelFetch(u_lights, ivec2(a_light, 0), 0)')
+    if backend == 'mesa':
+        head = ENGINE_VERSION_LINE
+    else:
+        text = text.replace('precision mediump float;', '')
+        head = '#version 300 es\nprecision highp float;\nprecision highp int;\nprecision highp sampler2D;\n'
+        text = text.replace('uniform samplerBuffer u_lights;', 'uniform sampler2D u_lights;')
+        text = text.replace('texelFetch(u_lights, a_light)', 'texelFetch(u_lights, ivec2(a_light, 0), 0)')
     if mode == 'varyings' and stage == 'frag':   # auxiliary pass: the varyings SwiftShader interpolated at this pixel
         text, n = re.subn(r'color = texture\(u_palette, vec2\(palette_index\.r,[^;]*;', 'color = vec3(v_tile_uv, v_dist);', text)
         if n == 0:
@@ -158,14 +176,95 @@ class _GL:
             raise RuntimeError('GL error 0x%x at %s' % (err, where))
 
 
-_gl = None
+class _Namespace:
+    pass
+
+
+class _GLMesa:
+    """Desktop OpenGL (core profile) on Mesa's llvmpipe through tests/mesa_headless.c: the same attribute names as _GL
+    (`gles` = the entry points, by _glapi_get_proc_address), so that GLReference drives either."""
+
+    def __init__(self):
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        lib = os.path.join(here, '_build', 'libmesa_headless.so')
+        src = os.path.join(here, 'mesa_headless.c')
+        if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+            os.makedirs(os.path.dirname(lib), exist_ok=True)
+            tmp = '%s.%d.tmp' % (lib, os.getpid())
+            subprocess.check_call(['gcc', '-shared', '-fPIC', '-O1', '-o', tmp, src, '-ldl'])
+            os.replace(tmp, lib)
+        self.lib = ctypes.CDLL(lib)
+        self.lib.mesa_headless_error.restype = ctypes.c_char_p
+        self.lib.mesa_headless_proc.restype = ctypes.c_void_p
+        self.lib.mesa_headless_proc.argtypes = [ctypes.c_char_p]
+        if self.lib.mesa_headless_init(MESA_DRIVER.encode(), MESA_GLAPI.encode(), 3, 3) != 0:
+            raise RuntimeError('mesa_headless_init: ' + self.lib.mesa_headless_error().decode())
+        vp, ci, cu, cf, cb = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_float, ctypes.c_ubyte
+        pu, pi, cs = ctypes.POINTER(cu), ctypes.POINTER(ci), ctypes.c_char_p
+        table = {
+            'glGetString': (cs, [cu]), 'glGetError': (cu, []), 'glGetIntegerv': (None, [cu, pi]),
+            'glCreateShader': (cu, [cu]), 'glShaderSource': (None, [cu, ci, ctypes.POINTER(cs), vp]), 'glCompileShader': (None, [cu]),
+            'glGetShaderiv': (None, [cu, cu, pi]), 'glGetProgramiv': (None, [cu, cu, pi]),
+            'glGetShaderInfoLog': (None, [cu, ci, vp, cs]), 'glGetProgramInfoLog': (None, [cu, ci, vp, cs]),
+            'glCreateProgram': (cu, []), 'glAttachShader': (None, [cu, cu]), 'glLinkProgram': (None, [cu]), 'glUseProgram': (None, [cu]),
+            'glGetUniformLocation': (ci, [cu, cs]), 'glGetAttribLocation': (ci, [cu, cs]),
+            'glGenBuffers': (None, [ci, pu]), 'glGenTextures': (None, [ci, pu]), 'glGenFramebuffers': (None, [ci, pu]),
+            'glGenRenderbuffers': (None, [ci, pu]), 'glGenVertexArrays': (None, [ci, pu]),
+            'glDeleteBuffers': (None, [ci, pu]), 'glDeleteTextures': (None, [ci, pu]), 'glDeleteFramebuffers': (None, [ci, pu]),
+            'glDeleteRenderbuffers': (None, [ci, pu]),
+            'glBindBuffer': (None, [cu, cu]), 'glBufferData': (None, [cu, ctypes.c_ssize_t, vp, cu]), 'glBindVertexArray': (None, [cu]),
+            'glBindTexture': (None, [cu, cu]), 'glActiveTexture': (None, [cu]), 'glPixelStorei': (None, [cu, ci]),
+            'glTexImage2D': (None, [cu, ci, ci, ci, ci, ci, cu, cu, vp]), 'glTexParameteri': (None, [cu, cu, ci]),
+            'glTexBuffer': (None, [cu, cu, cu]),
+            'glBindFramebuffer': (None, [cu, cu]), 'glBindRenderbuffer': (None, [cu, cu]),
+            'glRenderbufferStorage': (None, [cu, cu, ci, ci]), 'glFramebufferRenderbuffer': (None, [cu, cu, cu, cu]),
+            'glCheckFramebufferStatus': (cu, [cu]),
+            'glEnableVertexAttribArray': (None, [cu]), 'glDisableVertexAttribArray': (None, [cu]),
+            'glVertexAttribPointer': (None, [cu, ci, cu, cb, ci, vp]), 'glVertexAttribIPointer': (None, [cu, ci, cu, ci, vp]),
+            'glUniformMatrix4fv': (None, [ci, ci, cb, vp]), 'glUniform1f': (None, [ci, cf]), 'glUniform2f': (None, [ci, cf, cf]),
+            'glUniform1i': (None, [ci, ci]),
+            'glViewport': (None, [ci, ci, ci, ci]), 'glEnable': (None, [cu]), 'glDisable': (None, [cu]), 'glDepthFunc': (None, [cu]),
+            'glDepthMask': (None, [cb]), 'glFrontFace': (None, [cu]), 'glCullFace': (None, [cu]),
+            'glClearColor': (None, [cf, cf, cf, cf]), 'glClearDepthf': (None, [cf]), 'glClear': (None, [cu]),
+            'glDrawElements': (None, [cu, ci, cu, vp]), 'glDrawArrays': (None, [cu, ci, ci]),
+            'glReadPixels': (None, [ci, ci, ci, ci, cu, cu, vp]), 'glFinish': (None, []),
+        }
+        g = self.gles = _Namespace()
+        for name, (res, args) in table.items():
+            addr = self.lib.mesa_headless_proc(name.encode())
+            if not addr:
+                raise RuntimeError('Mesa does not export ' + name)
+            setattr(g, name, ctypes.CFUNCTYPE(res, *args)(addr))
+        self.version = g.glGetString(0x1F02).decode()
+        self.renderer = g.glGetString(0x1F01).decode()
+        self.glsl_version = g.glGetString(0x8B8C).decode()
+        bits = ci()
+        g.glGetIntegerv(0x0D50, ctypes.byref(bits))
+        self.subpixel_bits = bits.value
+        vao = cu()
+        g.glGenVertexArrays(1, ctypes.byref(vao))   # the core profile has no default vertex array object
+        g.glBindVertexArray(vao.value)
+
+    gen = _GL.gen
+    check = _GL.check
+
+
+_backends = {}
+_active = 'swiftshader'
+
+
+def use_backend(name):
+    """makes `name` ('swiftshader' | 'mesa') the GL that gl() returns (each has its own context, created on first use)"""
+    global _active
+    assert name in ('swiftshader', 'mesa')
+    _active = name
 
 
 def gl():
-    global _gl
-    if _gl is None:
-        _gl = _GL()
-    return _gl
+    if _active not in _backends:
+        _backends[_active] = _GLMesa() if _active == 'mesa' else _GL()
+    return _backends[_active]
 
 
 def _program(vert_src, frag_src):
@@ -229,8 +328,10 @@ def _rg8(a16):
 class GLReference:
     """The reference's GL draw path for one level (arrays keyed like BuiltLevel.arrays())."""
 
-    def __init__(self, lvl):
+    def __init__(self, lvl, backend='swiftshader'):
         get = (lambda k, d=None: lvl.get(k, d)) if isinstance(lvl, dict) else (lambda k, d=None: getattr(lvl, k, d))
+        self.backend = backend
+        use_backend(backend)
         G = gl()
         g = G.gles
         self.draws = np.asarray(get('draws'), np.uint32).reshape(-1, 4)
@@ -285,14 +386,17 @@ class GLReference:
         self.tex['palette'] = _texture(self.palette_rgb, 256, 32, GL_RGB8, GL_RGB, GL_CLAMP_TO_EDGE)
         self.lights_tex = G.gen(g.glGenTextures)
         self.sky_band = float(get('sky_band', 0.0))
-        self.programs = {}
+        self.programs, self.sources = {}, {}
+        if backend == 'mesa':   # u_lights is the reference's samplerBuffer: a GL_R8 buffer texture (game_shaders.rs:152-159)
+            self.lights_buf = G.gen(g.glGenBuffers)
         for mode in ('colour', 'ids', 'varyings'):
             for name in ('static', 'sky', 'sprite'):
                 src = {}
                 for stage in ('vert', 'frag'):
                     with open(os.path.join(REFERENCE_SHADERS, '%s.%s' % (name, stage))) as f:
-                        src[stage] = patch_shader(f.read(), stage, mode)
+                        src[stage] = patch_shader(f.read(), stage, mode, backend)
                 self.programs[(name, mode)] = _program(src['vert'], src['frag'])
+                self.sources[(name, mode)] = src
         self.fbos = {}
         G.check('level upload')
 
@@ -340,6 +444,7 @@ class GLReference:
         mode 'ids': auxiliary pass, returns (height, width) primitive ids, NO_PRIM where nothing was drawn.
         mode 'varyings': auxiliary pass into an RGBA32F target, returns (height, width, 3) float32 =
         (v_tile_uv.x, v_tile_uv.y, v_dist) for static / sprite fragments, (folded sky uv, -1) for sky fragments."""
+        use_backend(self.backend)
         G = gl()
         g = G.gles
         ids = mode == 'ids'
@@ -361,13 +466,19 @@ class GLReference:
         g.glClear(GL_COLOR_BUFFER_BIT | GL_DEPTH_BUFFER_BIT)
         # u_lights: 256 normalised u8
         g.glActiveTexture(GL_TEXTURE0 + 3)
-        g.glBindTexture(GL_TEXTURE_2D, self.lights_tex)
         li = np.ascontiguousarray(lights, np.uint8).reshape(256)
-        g.glPixelStorei(GL_UNPACK_ALIGNMENT, 1)
-        g.glTexImage2D(GL_TEXTURE_2D, 0, GL_R8, 256, 1, 0, GL_RED, GL_UNSIGNED_BYTE, li.ctypes.data_as(ctypes.c_void_p))
-        for pname, val in ((GL_TEXTURE_MIN_FILTER, GL_NEAREST), (GL_TEXTURE_MAG_FILTER, GL_NEAREST),
-                           (GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE), (GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE)):
-            g.glTexParameteri(GL_TEXTURE_2D, pname, val)
+        if self.backend == 'mesa':
+            g.glBindBuffer(GL_TEXTURE_BUFFER, self.lights_buf)
+            g.glBufferData(GL_TEXTURE_BUFFER, 256, li.ctypes.data_as(ctypes.c_void_p), GL_STATIC_DRAW)
+            g.glBindTexture(GL_TEXTURE_BUFFER, self.lights_tex)
+            g.glTexBuffer(GL_TEXTURE_BUFFER, GL_R8, self.lights_buf)
+        else:
+            g.glBindTexture(GL_TEXTURE_2D, self.lights_tex)
+            g.glPixelStorei(GL_UNPACK_ALIGNMENT, 1)
+            g.glTexImage2D(GL_TEXTURE_2D, 0, GL_R8, 256, 1, 0, GL_RED, GL_UNSIGNED_BYTE, li.ctypes.data_as(ctypes.c_void_p))
+            for pname, val in ((GL_TEXTURE_MIN_FILTER, GL_NEAREST), (GL_TEXTURE_MAG_FILTER, GL_NEAREST),
+                               (GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE), (GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE)):
+                g.glTexParameteri(GL_TEXTURE_2D, pname, val)
         pr = np.ascontiguousarray(projection, np.float32).reshape(16)
         mv0 = np.ascontiguousarray(modelview, np.float32).reshape(16)
         om = None if object_modelviews is None else np.ascontiguousarray(object_modelviews, np.float32).reshape(-1, 16)
