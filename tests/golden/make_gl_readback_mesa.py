@@ -10,7 +10,9 @@ that the GPU box -- which has neither Mesa's headers nor the reference checkout 
 what Mesa drew, the readbacks themselves (RGB + the primitive Mesa's rasteriser chose) of the 27 golden poses at 320x200 and of
 pose 0 of the benchmark sweep at 1920x1080.
 
-    python tests/golden/make_gl_readback_mesa.py [--jobs N]     # needs /root/reference + Mesa's swrast_dri.so
+    python tests/golden/make_gl_readback_mesa.py            # needs /root/reference + Mesa's swrast_dri.so
+    python tests/golden/make_gl_readback_mesa.py --extra    # census_mesa_extra.json: a wider net, counts only -- 60 IWADs of fresh generator
+                                                            # seeds x 3 levels x 2 poses at random sizes / times, half with displaced doors
 """
 import json
 import os
@@ -44,7 +46,29 @@ def stored_frames():
     return frames
 
 
-def one_frame(lv, glref, oracle, pose, w, h, obj_seed, keep=False):
+def describe_others(lv, mv, pr, t, lights, w, h, om, where, prim, gid, var, ovar):
+    """what the census could NOT attribute to a discontinuity, pixel by pixel: same winner or not, how thin the winning triangle is
+    on the screen (its height over its longest edge, in pixels), how far the ORACLE's own binary32 varyings are from the float64 ones"""
+    f64 = gl_census.F64Frame(lv, mv, pr, t, lights, w, h, om)
+    out = []
+    for ix, iy, label in where:
+        if label != 'other':
+            continue
+        op, gp = int(prim[iy, ix]), int(gid[iy, ix])
+        rec = {'x': ix, 'y': iy, 'same_winner': (op & 0xFFFFFF) == (gp & 0xFFFFFF)}
+        if rec['same_winner'] and op != 0xFFFFFFFF:
+            s, c = f64._tri(op), f64.sample(op, ix + 0.5, iy + 0.5)
+            rec['edge_margin_px'] = float(c['margin']) if c is not None else None
+            if c is not None and 'tuv' in c and ovar is not None:
+                rec['oracle_uv_off_texels'] = float(max(abs(float(ovar[iy, ix, 0]) - c['tuv'][0]), abs(float(ovar[iy, ix, 1]) - c['tuv'][1])))
+                rec['gl_uv_off_texels'] = float(max(abs(float(var[iy, ix, 0]) - c['tuv'][0]), abs(float(var[iy, ix, 1]) - c['tuv'][1])))
+                rec['oracle_dist_off_rel'] = float(abs(float(ovar[iy, ix, 2]) - c['dist']) / c['dist'])
+                rec['crosses_eye_plane'] = bool(s['wmin'] <= 0.0)
+        out.append(rec)
+    return out
+
+
+def one_frame(lv, glref, oracle, pose, w, h, obj_seed, keep=False, others=False):
     mv, pr, t = pose[:16], pose[16:32], float(pose[32])
     lights = lv.lights.fill_buffer_at(t)
     om = None if obj_seed is None else gen.moving_object_views(lv, mv, obj_seed)
@@ -52,7 +76,11 @@ def one_frame(lv, glref, oracle, pose, w, h, obj_seed, keep=False):
     gid = glref.render(mv, pr, t, lights, w, h, mode='ids', object_modelviews=om)
     var = glref.render(mv, pr, t, lights, w, h, mode='varyings', object_modelviews=om)
     fb, prim = oracle.render(mv, pr, t, lights, w, h, want_prim=True, object_modelviews=om)
-    c = gl_census.census(lv, mv, pr, t, lights, w, h, fb, prim, rgb, gid, var, object_modelviews=om)
+    c = gl_census.census(lv, mv, pr, t, lights, w, h, fb, prim, rgb, gid, var, object_modelviews=om, detail=others)
+    if others:
+        where = c.pop('where')
+        c['others'] = describe_others(lv, mv, pr, t, lights, w, h, om, where, prim, gid, var,
+                                      oracle.render_varyings(mv, pr, t, lights, w, h)[2] if om is None else None) if c['other'] else []
     r = gl_census.fragment_exact(oracle, lv, t, lights, rgb, gid, var)
     c['fragment_exact'] = {k: r[k] for k in ('pixels', 'disagree', 'by_kind', 'sky_sampler_boundary', 'row_division_boundary')}
     return c, ((rgb, gid) if keep else None)
@@ -98,5 +126,47 @@ def main():
         json.dump(census, f, indent=1, sort_keys=True)
 
 
+EXTRA_SEEDS = range(31000, 31060)
+EXTRA_SIZES = [(320, 200), (640, 400), (964, 540), (1280, 720), (712, 296), (1366, 768)]
+
+
+def extra_frames():
+    """(key, level key, width, height, pose[33], object seed or None): levels no committed fixture was produced from"""
+    out = []
+    for seed in EXTRA_SEEDS:
+        rng = np.random.RandomState(seed)
+        for index in range(3):
+            key = 'seed%d:%d' % (seed, index)
+            for k in range(2):
+                w, h = EXTRA_SIZES[rng.randint(len(EXTRA_SIZES))]
+                i = int(rng.randint(1024))
+                t = float(rng.choice([0.0, round(rng.uniform(0.0, 40.0), 1)]))
+                if t > 0.0 and abs(t * 35.0 / 8.0 - round(t * 35.0 / 8.0)) < 1e-3:
+                    t += 0.05   # not ON a boundary of static.vert's animation period (8 / 35 s): binary32 (GL, oracle) and the census's float64 model floor t / period differently there
+                out.append(('seed%d_L%d_sweep%d_t%.1f_%dx%d' % (seed, index, i, t, w, h), key, w, h, gen.sweep_pose(key, w, h, i, time=t),
+                            (5000 + seed + index) if rng.randint(2) else None))
+    return out
+
+
+def main_extra():
+    census = {'frames': {}}
+    for key, index, w, h, pose, obj_seed in extra_frames():
+        path, li = gen.wad_of(index)
+        lv = wad_oracle.build_level(path, META_PATH, li)
+        c, _ = one_frame(lv, gl_readback.GLReference(lv, backend='mesa'), raster.RasterOracle(lv), np.asarray(pose, np.float32), w, h, obj_seed, others=True)
+        c.update(level=index, width=w, height=h, time=float(pose[32]), objects_seed=obj_seed)
+        census['frames'][key] = c
+        print(key, {k: v for k, v in c.items() if k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES}, flush=True)
+    G = gl_readback.gl()
+    census.update(gl_version=G.version, gl_renderer=G.renderer, shader_head=gl_readback.ENGINE_VERSION_LINE, jitter_px=gl_census.JITTER)
+    census['total'] = {k: sum(f[k] for f in census['frames'].values()) for k in ('pixels', 'mismatch', 'winner_mismatch') + gl_census.CLASSES}
+    census['fragment_exact_total'] = gen.fragment_exact_total(census['frames'])
+    census['fragment_exact_total']['row_division_boundary'] = sum(f['fragment_exact']['row_division_boundary'] for f in census['frames'].values())
+    print('total', census['total'], 'mismatch fraction %.5f' % (census['total']['mismatch'] / census['total']['pixels']))
+    print('fragment stage', census['fragment_exact_total'])
+    with open(os.path.join(OUT, 'census_mesa_extra.json'), 'w') as f:
+        json.dump(census, f, indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
-    main()
+    main_extra() if '--extra' in sys.argv else main()
