@@ -13,7 +13,7 @@
  *                       game/src/vertex.rs:30-40, quad emission game/src/level.rs:764-793
  *
  * OpenGL leaves sub-ulp behaviour to the driver, so "the arithmetic" is pinned HERE and in
- * DESIGN.md section "Raster arithmetic" -- binary32, explicit operation order, fmaf only where
+ * DESIGN.md section "Raster arithmetic" -- binary32 (the triangle set-up S3..S5: binary64), explicit operation order, fmaf only where
  * written, no contraction (build with -ffp-contract=off).  The HIP kernels are written
  * independently against that text; this file is the checker.  It is never linked into the product.
  *
@@ -122,11 +122,6 @@ static void xform(const float *pm, const float *pos, float *clip) {
     clip[r] = fmaf(pm[8 + r], pos[2], fmaf(pm[4 + r], pos[1], fmaf(pm[0 + r], pos[0], pm[12 + r])));
 }
 
-static float dop(float a, float b, float c, float d) { /* a*b - c*d, each product rounded (symmetric) */
-  float p = a * b, q = c * d;
-  return p - q;
-}
-
 /* Triangle setup: DESIGN.md "Raster arithmetic" steps S1..S6.  Returns 0 if culled. */
 static int setup_tri(const float clip[3][4], const float u[3], const float v[3], int width, int height, float zk,
                      Setup *s) {
@@ -138,31 +133,38 @@ static int setup_tri(const float clip[3][4], const float u[3], const float v[3],
     yw[i] = (clip[i][1] + clip[i][3]) * hh;
     w[i] = clip[i][3];
   }
+  /* S3..S5 in BINARY64 on the binary32 inputs (round 6): every product of two binary32 values is exact in binary64, so an edge
+   * coefficient is ONE rounded difference -- and still exactly the negative of the neighbouring triangle's across a shared edge --,
+   * and the determinant and the plane numerators no longer lose their leading digits where a triangle is thin on the screen (found
+   * by the census against Mesa: the binary32 set-up put u/w, v/w, 1/w up to 3 texels / 0.1 % off there).  Each operation below is one
+   * IEEE binary64 operation (no contraction); the stored coefficients are those values rounded to binary32. */
+  double ed[3][3];
   for (int i = 0; i < 3; i++) {
     int j = (i + 1) % 3, k = (i + 2) % 3;
-    s->e[i][0] = dop(yw[j], w[k], yw[k], w[j]);
-    s->e[i][1] = dop(xw[k], w[j], xw[j], w[k]);
-    s->e[i][2] = dop(xw[j], yw[k], xw[k], yw[j]);
+    ed[i][0] = (double)yw[j] * (double)w[k] - (double)yw[k] * (double)w[j];
+    ed[i][1] = (double)xw[k] * (double)w[j] - (double)xw[j] * (double)w[k];
+    ed[i][2] = (double)xw[j] * (double)yw[k] - (double)xw[k] * (double)yw[j];
+    for (int c = 0; c < 3; c++) s->e[i][c] = (float)ed[i][c];
     s->tl[i] = (s->e[i][0] > 0.0f) || (s->e[i][0] == 0.0f && s->e[i][1] > 0.0f);
   }
-  float det = fmaf(w[0], s->e[0][2], fmaf(yw[0], s->e[0][1], xw[0] * s->e[0][0]));
-  if (!(det > 0.0f)) return 0; /* cull clockwise + degenerate (renderer.rs:55) */
+  const double det = (double)w[0] * ed[0][2] + ((double)yw[0] * ed[0][1] + (double)xw[0] * ed[0][0]);
+  if (!(det > 0.0)) return 0; /* cull clockwise + degenerate (renderer.rs:55) */
   /* S5: interpolate the residual Z - zk * W (zk = P[2][2] / P[2][3]; the constant P[3][2] for a perspective matrix),
    * not Z itself: the part zk * W interpolates to zk exactly, so rounding in the edge functions no longer leaks
    * |Z| ~ |W| into window depth (found by the GL-readback census: far slivers lost to surfaces behind them) */
   float rz[3];
   for (int i = 0; i < 3; i++) rz[i] = fmaf(-zk, clip[i][3], clip[i][2]);
   for (int c = 0; c < 3; c++) {
-    float nz = fmaf(rz[2], s->e[2][c], fmaf(rz[1], s->e[1][c], rz[0] * s->e[0][c]));
-    float n1 = (s->e[0][c] + s->e[1][c]) + s->e[2][c];
-    float nu = fmaf(u[2], s->e[2][c], fmaf(u[1], s->e[1][c], u[0] * s->e[0][c]));
-    float nv = fmaf(v[2], s->e[2][c], fmaf(v[1], s->e[1][c], v[0] * s->e[0][c]));
-    s->zp[c] = 0.5f * (nz / det);
-    s->wp[c] = n1 / det;
-    s->up[c] = nu / det;
-    s->vp[c] = nv / det;
+    const double nz = (double)rz[2] * ed[2][c] + ((double)rz[1] * ed[1][c] + (double)rz[0] * ed[0][c]);
+    const double n1 = (ed[0][c] + ed[1][c]) + ed[2][c];
+    const double nu = (double)u[2] * ed[2][c] + ((double)u[1] * ed[1][c] + (double)u[0] * ed[0][c]);
+    const double nv = (double)v[2] * ed[2][c] + ((double)v[1] * ed[1][c] + (double)v[0] * ed[0][c]);
+    const double zp = 0.5 * (nz / det);
+    s->zp[c] = (float)(c == 2 ? zp + (0.5 * (double)zk + 0.5) : zp);
+    s->wp[c] = (float)(n1 / det);
+    s->up[c] = (float)(nu / det);
+    s->vp[c] = (float)(nv / det);
   }
-  s->zp[2] = s->zp[2] + fmaf(0.5f, zk, 0.5f);
   /* bbox: part of the coverage definition */
   float wmin = fminf(w[0], fminf(w[1], w[2]));
   s->x0 = 0;

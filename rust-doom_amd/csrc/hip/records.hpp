@@ -147,11 +147,6 @@ struct DeviceLevelView {
 __device__ __forceinline__ float plane3(const float *p, float px, float py) {
   return fmaf(p[0], px, fmaf(p[1], py, p[2]));
 }
-__device__ __forceinline__ float dop(float a, float b, float c, float d) {
-  float p = a * b;
-  float q = c * d;
-  return p - q;
-}
 __device__ __forceinline__ float glsl_mod(float x, float y) { return x - y * floorf(x / y); }
 
 

@@ -133,20 +133,28 @@ __device__ __forceinline__ bool setup_triangle(const LevelSlice &lv, const PoseC
           yw[i] = (clip[i][1] + clip[i][3]) * hh;
           w[i] = clip[i][3];
         }
+        // S3..S5 in BINARY64 on the binary32 inputs (round 6): a product of two binary32 values is exact in
+        // binary64, so an edge coefficient is ONE rounded difference -- still exactly the negative of the neighbouring triangle's
+        // across a shared edge -- and the determinant and the plane numerators keep their leading digits where a triangle is thin on
+        // the screen (the census against Mesa found u/w, v/w, 1/w up to 3 texels / 0.1 % off there with the binary32 set-up).  Every
+        // operation is one IEEE binary64 operation (the unit is compiled with -ffp-contract=off); what the records store is
+        // rounded to binary32 once.  The cull kernel's instantiation runs the same operations up to the determinant's sign.
         uint32_t tl = 0;
+        double ed[9];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
           const int j = (i + 1) % 3, k = (i + 2) % 3;
-          const float A = dop(yw[j], w[k], yw[k], w[j]);
-          const float B = dop(xw[k], w[j], xw[j], w[k]);
-          const float C = dop(xw[j], yw[k], xw[k], yw[j]);
+          ed[3 * i] = (double)yw[j] * (double)w[k] - (double)yw[k] * (double)w[j];
+          ed[3 * i + 1] = (double)xw[k] * (double)w[j] - (double)xw[j] * (double)w[k];
+          ed[3 * i + 2] = (double)xw[j] * (double)yw[k] - (double)xw[k] * (double)yw[j];
+          const float A = (float)ed[3 * i], B = (float)ed[3 * i + 1], C = (float)ed[3 * i + 2];
           rr.e[3 * i] = A;
           rr.e[3 * i + 1] = B;
           rr.e[3 * i + 2] = C;
           if ((A > 0.0f) || (A == 0.0f && B > 0.0f)) tl |= 1u << i;
         }
-        const float det = fmaf(w[0], rr.e[2], fmaf(yw[0], rr.e[1], xw[0] * rr.e[0]));
-        ok = det > 0.0f;
+        const double det = (double)w[0] * ed[2] + ((double)yw[0] * ed[1] + (double)xw[0] * ed[0]);
+        ok = det > 0.0;
         if (ok) {
           // S5: the depth plane interpolates Z - zk * W (a small residual: the constant P[3][2] for a perspective
           // matrix) instead of Z, whose dominant part zk * W interpolates to the constant zk exactly; errors of the
@@ -155,17 +163,17 @@ __device__ __forceinline__ bool setup_triangle(const LevelSlice &lv, const PoseC
                                fmaf(-pc.zk, clip[2][3], clip[2][2])};
 #pragma unroll
           for (int c = 0; c < 3; c++) {
-            const float e0 = rr.e[c], e1 = rr.e[3 + c], e2 = rr.e[6 + c];
-            const float nz = fmaf(rz[2], e2, fmaf(rz[1], e1, rz[0] * e0));
-            const float n1 = (e0 + e1) + e2;
-            const float nu = fmaf(u[2], e2, fmaf(u[1], e1, u[0] * e0));
-            const float nv = fmaf(v[2], e2, fmaf(v[1], e1, v[0] * e0));
-            rr.zp[c] = 0.5f * (nz / det);
-            sr.wp[c] = n1 / det;
-            sr.up[c] = nu / det;
-            sr.vp[c] = nv / det;
+            const double e0 = ed[c], e1 = ed[3 + c], e2 = ed[6 + c];
+            const double nz = (double)rz[2] * e2 + ((double)rz[1] * e1 + (double)rz[0] * e0);
+            const double n1 = (e0 + e1) + e2;
+            const double nu = (double)u[2] * e2 + ((double)u[1] * e1 + (double)u[0] * e0);
+            const double nv = (double)v[2] * e2 + ((double)v[1] * e1 + (double)v[0] * e0);
+            const double zp = 0.5 * (nz / det);
+            rr.zp[c] = (float)(c == 2 ? zp + (0.5 * (double)pc.zk + 0.5) : zp);
+            sr.wp[c] = (float)(n1 / det);
+            sr.up[c] = (float)(nu / det);
+            sr.vp[c] = (float)(nv / det);
           }
-          rr.zp[2] = rr.zp[2] + fmaf(0.5f, pc.zk, 0.5f);
           int x0 = 0, y0 = 0, x1 = width - 1, y1 = height - 1;
           const float wmin = fminf(w[0], fminf(w[1], w[2]));
           wkey = wmin;

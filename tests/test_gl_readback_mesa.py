@@ -5,7 +5,7 @@ on the same 204 frames as tests/test_gl_readback.py (SwiftShader, OpenGL ES 3.0,
 
 Why a second one: round 5's review -- "bit-exact vs GL readback is 99.16-99.54 %, not 100 %, and it is ONE GL implementation".
 Mesa interpolates perspective in full binary32 and snaps vertices to 1/256 pixel (SwiftShader: ~13 bits, 1/16 pixel), so the
-oracle's frames differ from ITS readbacks in a tenth as many pixels (bounds below; measured numbers in census_mesa.json), every
+oracle's frames differ from ITS readbacks in a fifteenth to a fortieth as many pixels (0.022 % of the stored, 0.031 % of the extended ones; bounds below), every
 one again explained by a discontinuity GL leaves open (tests/gl_census.py, unchanged: `other` == 0 in all frames), and the
 fragment stage on its own is exact again: the oracle's binary32 static.frag / sprite.frag arithmetic on the varyings Mesa
 itself interpolated reproduces Mesa's colour at every flat / wall / decor pixel.
@@ -31,7 +31,7 @@ FRAMES = np.load(os.path.join(OUT, 'frames_mesa.npz'))
 SS = json.load(open(os.path.join(OUT, 'census.json')))   # SwiftShader's census of the same frames
 STORED = sorted(k[:-4] for k in FRAMES.files if k.endswith('_rgb'))
 
-MAX_MISMATCH_TOTAL = 0.002          # of all pixels (SwiftShader's bound: 0.02)
+MAX_MISMATCH_TOTAL = 0.0005         # of all pixels (measured: 0.00022 stored, 0.00031 extended; SwiftShader's bound: 0.02)
 MAX_MISMATCH_FRAME = 0.01           # of one frame's pixels, coplanar-wall depth ties aside (SwiftShader's: 0.05)
 MAX_WINNER_MISMATCH_TOTAL = 0.001
 
@@ -50,7 +50,7 @@ def test_census_is_clean_and_bounded(part, total):
     assert tot['other'] == 0 and all(f['other'] == 0 for f in CENSUS[part].values())
     assert tot['mismatch'] <= MAX_MISMATCH_TOTAL * tot['pixels'], tot
     assert tot['winner_mismatch'] <= MAX_WINNER_MISMATCH_TOTAL * tot['pixels'], tot
-    assert tot['mismatch'] * 5 <= SS[total]['mismatch']        # a different rasteriser and interpolator: far fewer open discontinuities hit
+    assert tot['mismatch'] * 10 <= SS[total]['mismatch']       # a different rasteriser and interpolator: far fewer open discontinuities hit
     for k, f in CENSUS[part].items():
         assert f['mismatch'] - f['depth tie'] <= MAX_MISMATCH_FRAME * f['pixels'], (k, f)
         assert sum(f[c] for c in gl_census.CLASSES) == f['mismatch'], k
@@ -186,29 +186,23 @@ EXTRA = json.load(open(os.path.join(OUT, 'census_mesa_extra.json')))
 
 def test_wider_net_over_fresh_seeds():
     """60 IWADs of fresh generator seeds x 3 levels x 2 poses, random sizes from 320x200 to 1366x768, random times, half of them
-    with every door / lift displaced: 190.6 M pixels against Mesa.  99.945 % identical (depth ties of coplanar displaced walls are
-    two thirds of the rest); the fragment stage on Mesa's varyings disagrees at 11 wall pixels, all on a COLORMAP-row boundary.
-    THIRTEEN pixels in 9 frames are NOT attributed to a discontinuity (`other`), and they are kept as such: in each the same
-    primitive wins on both sides, the pixel lies within a quarter of a pixel of an edge of a triangle that is thin on the screen,
-    Mesa's interpolated varyings sit within 5e-4 texels of the float64 value -- and the ORACLE's (the specification's: binary32
-    planes n / det evaluated at absolute pixel coordinates) are off by 0.02 to 3 texels: the plane set-up is
-    ill-conditioned where det is small against the edge coefficients.  A finding about the specification, 7e-8 of the pixels;
-    HIP == oracle there as everywhere (DESIGN section 8 lists the re-anchored planes that would remove it)."""
+    with every door / lift displaced: 190.6 M pixels against Mesa.  99.949 % identical (depth ties of coplanar displaced walls are
+    three quarters of the rest), every other pixel attributed to a discontinuity: `other` == 0 in all 360 frames; the fragment stage
+    on Mesa's varyings disagrees at 11 wall pixels, all on a COLORMAP-row boundary.
+    THIS NET IS WHAT CHANGED THE SPECIFICATION (round 6): with the binary32 triangle set-up of rounds 1-5 it held 13 pixels the
+    census could not attribute -- same winner on both sides, within a quarter of a pixel of an edge of a triangle that is thin on
+    the screen, Mesa's varyings within 5e-4 texels of the float64 value, the oracle's 0.02 to 3 texels off.  The error was the
+    set-up's alone (det and the plane numerators lose their leading digits there): S3..S5 now run in binary64 on the same binary32
+    inputs, which removed all 13, a third of ALL differences from Mesa on the stored frames (3 023 -> 2 412) and a
+    sixth on the extended ones (50 811 -> 43 102).  `others` (per-pixel descriptions of unattributed pixels) is therefore empty."""
     tot = EXTRA['total']
     assert len(EXTRA['frames']) == 360 and tot['pixels'] >= 190_000_000
-    assert tot['mismatch'] <= 0.001 * tot['pixels'] and tot['mismatch'] - tot['depth tie'] <= 0.0003 * tot['pixels'], tot
-    assert tot['other'] <= 2e-7 * tot['pixels'], tot
+    assert tot['mismatch'] <= 0.001 * tot['pixels'] and tot['mismatch'] - tot['depth tie'] <= 0.0002 * tot['pixels'], tot
+    assert tot['other'] == 0 and all(f['other'] == 0 and f['others'] == [] for f in EXTRA['frames'].values()), tot
     fe = EXTRA['fragment_exact_total']
     assert fe['disagree'] == fe['row_division_boundary'] + fe['sky_sampler_boundary'] and fe['disagree'] <= 2e-7 * fe['pixels'], fe
-    n = 0
     for k, f in EXTRA['frames'].items():
-        assert sum(f[c] for c in gl_census.CLASSES) == f['mismatch'] and len(f['others']) == f['other'], k
-        for o in f['others']:
-            n += 1
-            assert o['same_winner'] and o['edge_margin_px'] is not None and 0.0 <= o['edge_margin_px'] <= 0.25, (k, o)
-            if 'oracle_uv_off_texels' in o:   # (frames with displaced doors carry no oracle varyings: render_varyings has no per-object transforms)
-                assert o['gl_uv_off_texels'] <= 1e-3 and o['oracle_uv_off_texels'] >= 20.0 * o['gl_uv_off_texels'], (k, o)
-    assert n == tot['other']
+        assert sum(f[c] for c in gl_census.CLASSES) == f['mismatch'], k
 
 
 @needs_mesa
