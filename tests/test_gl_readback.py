@@ -24,7 +24,7 @@ What is asserted:
     disagreements are sky pixels within 1/64 texel of a texel boundary of sky.frag's REPEAT / NEAREST fetch, whose address
     arithmetic GL leaves to the sampler (38 stored pixels), each reproduced through the neighbouring texel.
 
-Bounds (measured: 0.84 % of the 10 982 400 stored pixels and 0.44 % of the 135 731 200 extended ones differ; 95 % of those
+Bounds (measured: 0.83 % of the 10 982 400 stored pixels and 0.45 % of the 138 035 200 extended ones differ; 95 % of those
 are texel-boundary picks caused by SwiftShader's ~13-bit perspective interpolation, 2.4 % lie on primitive edges; winners
 differ on 0.03 - 0.05 %):"""
 import importlib.util
