@@ -168,5 +168,59 @@ def main_extra():
         json.dump(census, f, indent=1, sort_keys=True)
 
 
+def extreme_frames():
+    """poses the sweep rarely produces (tests/stress_extreme_poses.py): eyes within centimetres of vertices, walls and floors or far
+    outside the level, pitches up to straight up / down -- triangles that cross the eye plane, leave the depth range inside a pixel
+    block, cover the whole frame"""
+    from util import reference_projection, view_matrix
+    out = []
+    for index, (w, h) in zip(range(9), [(640, 400), (964, 540), (324, 180), (1280, 720)] * 3):
+        rng = np.random.RandomState(77000 + index)
+        lv = wad_oracle.build_level(ensure_wad(), META_PATH, index)
+        verts = lv.static_vertices['a_pos']
+        for i in range(20):
+            v = verts[rng.randint(len(verts))].astype(np.float64)
+            kind = i % 4
+            if kind == 0:
+                eye = v + rng.uniform(-0.02, 0.02, 3)
+            elif kind == 1:
+                eye = v + np.array([rng.uniform(-0.3, 0.3), rng.choice([0.0, 1e-4, -1e-4]), rng.uniform(-0.3, 0.3)])
+            elif kind == 2:
+                eye = v * 1.0 + np.array([rng.uniform(-40, 40), rng.uniform(5, 60), rng.uniform(-40, 40)])
+            else:
+                eye = v + rng.uniform(-0.5, 0.5, 3)
+            pitch = rng.choice([rng.uniform(-1.57, 1.57), 1.5707, -1.5707, 0.0])
+            t = float(rng.choice([0.0, round(rng.uniform(0, 30), 2) + 0.013]))
+            pose = np.zeros(33, np.float32)
+            pose[:16], pose[16:32], pose[32] = view_matrix(eye, rng.uniform(0, 2 * np.pi), pitch), reference_projection(w, h), t
+            out.append(('L%d_extreme%d_k%d_%dx%d' % (index, i, kind, w, h), index, w, h, pose, None))
+    return out
+
+
+def main_net(frames, out_name):
+    census = {'frames': {}}
+    for key, index, w, h, pose, obj_seed in frames:
+        path, li = gen.wad_of(index)
+        lv = wad_oracle.build_level(path, META_PATH, li)
+        c, _ = one_frame(lv, gl_readback.GLReference(lv, backend='mesa'), raster.RasterOracle(lv), np.asarray(pose, np.float32), w, h, obj_seed, others=True)
+        c.update(level=index, width=w, height=h, time=float(pose[32]), objects_seed=obj_seed)
+        census['frames'][key] = c
+        print(key, {k: v for k, v in c.items() if k in ('mismatch', 'winner_mismatch') + gl_census.CLASSES}, flush=True)
+    G = gl_readback.gl()
+    census.update(gl_version=G.version, gl_renderer=G.renderer, shader_head=gl_readback.ENGINE_VERSION_LINE, jitter_px=gl_census.JITTER)
+    census['total'] = {k: sum(f[k] for f in census['frames'].values()) for k in ('pixels', 'mismatch', 'winner_mismatch') + gl_census.CLASSES}
+    census['fragment_exact_total'] = gen.fragment_exact_total(census['frames'])
+    census['fragment_exact_total']['row_division_boundary'] = sum(f['fragment_exact']['row_division_boundary'] for f in census['frames'].values())
+    print('total', census['total'], 'mismatch fraction %.5f' % (census['total']['mismatch'] / census['total']['pixels']))
+    print('fragment stage', census['fragment_exact_total'])
+    with open(os.path.join(OUT, out_name), 'w') as f:
+        json.dump(census, f, indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
-    main_extra() if '--extra' in sys.argv else main()
+    if '--extreme' in sys.argv:
+        main_net(extreme_frames(), 'census_mesa_extreme.json')
+    elif '--extra' in sys.argv:
+        main_extra()
+    else:
+        main()

@@ -221,3 +221,30 @@ def test_mesa_regenerates_counts_of_the_wider_net(key):
     for name in ('mismatch', 'winner_mismatch') + gl_census.CLASSES:
         assert got[name] == c[name], (name, got[name], c[name])
     assert got['fragment_exact'] == c['fragment_exact'] and len(got['others']) == c['other']
+
+
+# ---- poses the sweep rarely produces (counts only) -------------------------------------------------------------------------------
+EXTREME = json.load(open(os.path.join(OUT, 'census_mesa_extreme.json')))
+
+
+def test_extreme_poses_against_mesa():
+    """180 frames of tests/stress_extreme_poses.py's kind -- eyes within 2 cm of a vertex of the level, on the floor plane itself, far
+    outside looking back, pitches up to straight up / down -- on all nine levels, 75 M pixels: 99.935 % identical to Mesa's (87 % of the
+    rest are depth ties: from far outside the whole level collapses into a few depth steps), the fragment stage exact everywhere.
+    FOUR pixels of ONE frame (the eye 2 cm from a vertex, a wall that crosses the eye plane filling the frame) stay unattributed, and
+    are kept as such: the same primitive wins, texel coordinates agree to 1e-3 texels, but the oracle's 1/w -- the binary32 plane
+    evaluated at absolute pixel coordinates (F1), steep next to the eye plane -- is 4.3e-4 (relative) off the float64 value, just enough
+    to cross a COLORMAP-row boundary that the census's margin (2^-11 of v_dist) does not reach.  The per-pixel evaluation, not the
+    set-up (which is binary64 since this round); a pose the reference's player cannot take (its radius keeps the eye 16 map units
+    from a wall)."""
+    tot = EXTREME['total']
+    assert len(EXTREME['frames']) == 180 and tot['pixels'] >= 75_000_000
+    assert tot['mismatch'] - tot['depth tie'] <= 0.0002 * tot['pixels'] and tot['mismatch'] <= 0.001 * tot['pixels'], tot
+    fe = EXTREME['fragment_exact_total']
+    assert fe['disagree'] == 0 and fe['pixels'] >= 30_000_000, fe
+    assert tot['other'] <= 4 and sum(1 for f in EXTREME['frames'].values() if f['other']) <= 1, tot
+    for k, f in EXTREME['frames'].items():
+        assert sum(f[c] for c in gl_census.CLASSES) == f['mismatch'] and len(f['others']) == f['other'], k
+        for o in f['others']:
+            assert o['same_winner'] and o['crosses_eye_plane'] and o['oracle_uv_off_texels'] <= 2e-3 and o['gl_uv_off_texels'] <= 2e-4, (k, o)
+            assert 1e-4 <= o['oracle_dist_off_rel'] <= 1e-3, (k, o)
