@@ -201,3 +201,43 @@ def test_hip_matches_hand_derivation(prediction):
     out, safe = prediction
     bad = (fb != out) & safe
     assert bad.sum() == 0, 'HIP path differs from the hand derivation at %r' % (np.argwhere(bad)[:5],)
+
+
+def test_zero_area_fan_triangles_never_win(oracle_levels):
+    """The reference's floor / ceiling fans start with a triangle that repeats its first vertex (game/src/level.rs:636-645).  Since
+    round 6 the triangle set-up S3-S5 runs in binary64 on the binary32 inputs: the products of S3 are exact there,
+    the edge coefficients of a repeated vertex cancel EXACTLY, the determinant is 0 and S4 culls the triangle, as GL does.  (In
+    binary32 the rounded products left noise of either sign: half of those triangles were set up, binned and walked -- 7 % of the
+    visible triangles of the benchmark sweep -- and a few won pixels on the strength of that noise.)"""
+    from oracle import raster
+    poses = np.load(__import__('os').path.join(__import__('util').GOLDEN, 'poses.npy'))
+    for index in (0, 3, 7):
+        lv = oracle_levels(index)
+        tri = np.asarray(lv.static_indices).reshape(-1, 3)
+        degenerate = (tri[:, 0] == tri[:, 1]) | (tri[:, 1] == tri[:, 2]) | (tri[:, 0] == tri[:, 2])
+        assert degenerate.sum() > 50   # every flat polygon brings one
+        # static primitive ids = positions in the draw list; flats and walls are drawn from static_indices in draw order
+        draws = np.asarray(lv.draws).reshape(-1, 4)
+        first_prim = np.cumsum([0] + [int(c) // 3 for c in draws[:, 3]])
+        for k in range(poses.shape[1]):
+            p = poses[index, k]
+            t = float(p[32])
+            _fb, prim = raster.RasterOracle(lv).render(p[:16], p[16:32], t, lv.lights.fill_buffer_at(t), 320, 200, want_prim=True)
+            for pid in np.unique(prim[prim != raster.NO_PRIM]):
+                d = int(np.searchsorted(first_prim, pid, side='right') - 1)
+                if int(draws[d, 0]) in (0, 1):   # flat / wall: indices into static_indices
+                    i = int(draws[d, 2]) // 3 + int(pid - first_prim[d])
+                    assert not degenerate[i], (index, k, int(pid))
+
+
+@pytest.mark.gpu
+def test_hip_culls_the_zero_area_fan_triangle():
+    """the hand-built scene holds five triangles, one of them the fan's degenerate first: the renderer must call FOUR visible"""
+    import rust_doom_amd as rd
+    lvl, lights = kat_level()
+    mv, pr = pose()
+    poses = np.zeros(1, rd.POSE)
+    poses[0]['modelview'], poses[0]['projection'] = mv, pr
+    batch = rd.Batch(rd.DeviceLevel(lvl), W, H, 1)
+    batch.render(poses, lights, timed=True)
+    assert batch.render(poses, lights, timed=True)['visible_triangles'] == 4
