@@ -568,7 +568,7 @@ def run_threads(args):
     achieved = extras['my_px_per_step'] * ALG_READ_BYTES_PER_PIXEL / (frag * 1e-3) / 1e9 if frag > 0 else 0.0
     out = {'metric': metric_label(args, levels), 'value': round(poses_global * frame_px * args.steps / t / 1e6, 1), 'unit': 'Mpixels/s', 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(t / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling,
-           'vs_baseline': None, 'dtype': 'f32+u8', 'data': 'synthetic', 'frames_per_s': round(poses_global * args.steps / t, 1),
+           'vs_baseline': None, 'dtype': 'f32+u8 (triangle set-up f64)', 'data': 'synthetic', 'frames_per_s': round(poses_global * args.steps / t, 1),
            'config': {'workload': '%s, %d poses %s at %dx%d' % (metric_label(args, levels), args.poses, 'per GPU' if args.scaling == 'weak' else 'in total, cut into contiguous ranges',
                                                                  args.width, args.height),
                       'levels': levels, 'launcher': 'threads: one process, one host thread per GPU, C ABI only', 'streams': args.streams,
@@ -793,7 +793,7 @@ def main():
             'metric': metric_label(args, levels), 'value': round(total_px / elapsed / 1e6, 1),
             'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling,
-            'vs_baseline': None, 'dtype': 'f32+u8', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32+u8 (triangle set-up f64)', 'data': 'synthetic',
             'frames_per_s': round(poses_per_step_global * args.steps / elapsed, 1),
             # --steps K asks for AT LEAST K timed steps; the timed region is stretched to --long seconds (default 0.5: twenty steps
             # of 4.4 ms are 88 ms, a fifth of which is the ramp of the first step) and `steps` is the number really timed
