@@ -217,8 +217,17 @@ def main_net(frames, out_name):
         json.dump(census, f, indent=1, sort_keys=True)
 
 
+def large_frames():
+    """the 10 x E1M1 level (38 262 triangles) and the texture-rich stand-in (320 wall textures, a 4096 x 2048 atlas): other content than the nine levels"""
+    out = [('big_sweep%d_t%.1f_640x400' % (i, t), 'big', 640, 400, gen.sweep_pose('big', 640, 400, i, time=t), None)
+           for i, t in zip(range(5, 1024, 26), [0.0, 3.3, 0.0, 17.9] * 10)]
+    return out
+
+
 if __name__ == '__main__':
-    if '--extreme' in sys.argv:
+    if '--large' in sys.argv:
+        main_net(large_frames(), 'census_mesa_large.json')
+    elif '--extreme' in sys.argv:
         main_net(extreme_frames(), 'census_mesa_extreme.json')
     elif '--extra' in sys.argv:
         main_extra()

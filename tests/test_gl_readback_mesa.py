@@ -248,3 +248,16 @@ def test_extreme_poses_against_mesa():
         for o in f['others']:
             assert o['same_winner'] and o['crosses_eye_plane'] and o['oracle_uv_off_texels'] <= 2e-3 and o['gl_uv_off_texels'] <= 2e-4, (k, o)
             assert 1e-4 <= o['oracle_dist_off_rel'] <= 1e-3, (k, o)
+
+
+def test_the_large_level_against_mesa():
+    """40 frames of the 10 x E1M1 level (38 262 triangles, lists of hundreds of entries at the horizon) at 640x400, four of every ten
+    time-varying: 10.2 M pixels, 99.954 % identical to Mesa's, every other pixel attributed, the fragment stage exact but for one
+    COLORMAP-row-boundary pixel (counts only; tests/golden/make_gl_readback_mesa.py --large)"""
+    c = json.load(open(os.path.join(OUT, 'census_mesa_large.json')))
+    tot, fe = c['total'], c['fragment_exact_total']
+    assert len(c['frames']) == 40 and tot['pixels'] == 40 * 640 * 400
+    assert tot['other'] == 0 and tot['mismatch'] <= 0.001 * tot['pixels'], tot
+    assert fe['disagree'] == fe['row_division_boundary'] + fe['sky_sampler_boundary'] <= 2, fe
+    for k, f in c['frames'].items():
+        assert sum(f[x] for x in gl_census.CLASSES) == f['mismatch'] and f['others'] == [], k
